@@ -1,0 +1,136 @@
+"""Deterministic synthetic weights and frames.
+
+No trained weights and no GIRAFE/BAGLS data ship with the reference snapshot
+(`/root/reference/.MISSING_LARGE_BLOBS`), and there is no network.  Everything
+the tests, the golden-vector generator and ``bench.py`` feed to the U-Net is
+therefore synthesised here from ``numpy.random.RandomState`` streams, which
+are bit-stable across machines and numpy versions, so the GPU box regenerates
+exactly the tensors the fixtures under ``tests/golden/`` were captured with
+(no 31 MB weight file has to travel).
+
+State-dict layout follows the reference module tree
+(`openglottal/models/unet.py:50-72`): ``downs.{i}.net.{0,1,3,4}``,
+``bottleneck.net.*``, ``ups.{0,2,4,6}`` (ConvTranspose2d, with bias),
+``ups.{1,3,5,7}.net.*`` and ``head``.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+DEFAULT_FEATURES = (32, 64, 128, 256)
+
+
+def _conv_w(rs: np.random.RandomState, co: int, ci: int, k: int) -> np.ndarray:
+    # He-uniform keeps activation magnitudes O(1) through 18 conv+ReLU layers,
+    # so no layer degenerates to all-zero (which would hide indexing bugs).
+    bound = np.sqrt(6.0 / (ci * k * k))
+    return rs.uniform(-bound, bound, size=(co, ci, k, k)).astype(np.float32)
+
+
+def _bn(rs: np.random.RandomState, c: int, prefix: str, sd: dict) -> None:
+    # Non-trivial affine + running stats: default BN (γ=1, β=0, μ=0, σ²=1) is
+    # identity-ish and would hide scale/shift folding mistakes.
+    sd[prefix + ".weight"] = rs.uniform(0.8, 1.2, size=c).astype(np.float32)
+    sd[prefix + ".bias"] = rs.uniform(-0.1, 0.1, size=c).astype(np.float32)
+    sd[prefix + ".running_mean"] = rs.uniform(-0.1, 0.1, size=c).astype(np.float32)
+    sd[prefix + ".running_var"] = rs.uniform(0.5, 1.5, size=c).astype(np.float32)
+    sd[prefix + ".num_batches_tracked"] = np.array(100, dtype=np.int64)
+
+
+def _double_conv(rs, prefix: str, ci: int, co: int, sd: dict) -> None:
+    sd[prefix + ".net.0.weight"] = _conv_w(rs, co, ci, 3)
+    _bn(rs, co, prefix + ".net.1", sd)
+    sd[prefix + ".net.3.weight"] = _conv_w(rs, co, co, 3)
+    _bn(rs, co, prefix + ".net.4", sd)
+
+
+def make_unet_state_dict(
+    features=DEFAULT_FEATURES,
+    in_ch: int = 1,
+    out_ch: int = 1,
+    seed: int = 20260227,
+    head_scale: float = 1.0,
+    head_bias: float | None = None,
+) -> dict[str, np.ndarray]:
+    """Seeded numpy state_dict with the reference's key names and shapes.
+
+    ``head_scale``/``head_bias`` let a caller re-apply a head calibration that
+    was measured once with the reference model (see ``tests/golden``): random
+    weights otherwise put every logit on one side of zero and every mask is
+    all-0 or all-255.
+    """
+    rs = np.random.RandomState(seed)
+    sd: dict[str, np.ndarray] = {}
+    ch = in_ch
+    for i, f in enumerate(features):
+        _double_conv(rs, f"downs.{i}", ch, f, sd)
+        ch = f
+    _double_conv(rs, "bottleneck", ch, ch * 2, sd)
+    for j, f in enumerate(reversed(features)):
+        bound = np.sqrt(3.0 / (f * 2))
+        sd[f"ups.{2 * j}.weight"] = rs.uniform(-bound, bound, size=(f * 2, f, 2, 2)).astype(np.float32)
+        sd[f"ups.{2 * j}.bias"] = rs.uniform(-0.05, 0.05, size=f).astype(np.float32)
+        _double_conv(rs, f"ups.{2 * j + 1}", f * 2, f, sd)
+    bound = np.sqrt(3.0 / features[0])
+    hw = rs.uniform(-bound, bound, size=(out_ch, features[0], 1, 1)).astype(np.float32)
+    hb = rs.uniform(-0.05, 0.05, size=out_ch).astype(np.float32)
+    sd["head.weight"] = (hw * np.float32(head_scale)).astype(np.float32)
+    sd["head.bias"] = hb if head_bias is None else np.full(out_ch, head_bias, dtype=np.float32)
+    return sd
+
+
+def state_dict_to_torch(sd: dict[str, np.ndarray]):
+    import torch
+
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+
+
+# ── Frames ───────────────────────────────────────────────────────────────────
+
+
+def bench_frame_bgr(i: int, h: int = 256, w: int = 256) -> np.ndarray:
+    """Seeded counterpart of `scripts/benchmark_video_speed.py:69`."""
+    return np.random.RandomState(1234 + i).randint(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+def random_gray_frames(n: int, h: int = 256, w: int = 256, seed: int = 7) -> np.ndarray:
+    """``[n,h,w]`` uint8 noise frames (one RandomState stream; fast)."""
+    return np.random.RandomState(seed).randint(0, 256, (n, h, w), dtype=np.uint8)
+
+
+def bulk_gray_frames(n: int, h: int = 256, w: int = 256, seed: int = 1234) -> np.ndarray:
+    """Large synthetic grayscale 'video' for throughput runs (PCG64, ~1 GB/s)."""
+    return np.random.default_rng(seed).integers(0, 256, size=(n, h, w), dtype=np.uint8)
+
+
+def glottis_frames(
+    n_patients: int = 4, frames_per_patient: int = 20, h: int = 256, w: int = 256, seed: int = 99
+) -> tuple[np.ndarray, np.ndarray]:
+    """Structured stand-in for the 80-frame GIRAFE test split.
+
+    Bright textured background with a dark rotated ellipse whose opening
+    oscillates per "patient".  Returns ``(gray [N,h,w] u8, gt [N,h,w] u8 {0,255})``.
+    """
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    frames, gts = [], []
+    for _ in range(n_patients):
+        bg = rs.uniform(120, 220)
+        dark = rs.uniform(20, 60)
+        cx0, cy0 = w / 2 + rs.uniform(-20, 20), h / 2 + rs.uniform(-20, 20)
+        ang = rs.uniform(-0.4, 0.4)
+        a_max, b_len = rs.uniform(6, 12), rs.uniform(25, 60)
+        period = rs.uniform(16, 30)
+        phase = rs.uniform(0, 2 * np.pi)
+        for t in range(frames_per_patient):
+            a = max(0.0, a_max * 0.5 * (1 + np.sin(2 * np.pi * t / period + phase)) - 1.0)
+            cx, cy = cx0 + rs.uniform(-1, 1), cy0 + rs.uniform(-1, 1)
+            xr = (xx - cx) * np.cos(ang) + (yy - cy) * np.sin(ang)
+            yr = -(xx - cx) * np.sin(ang) + (yy - cy) * np.cos(ang)
+            inside = (xr / max(a, 1e-6)) ** 2 + (yr / b_len) ** 2 <= 1.0 if a > 0 else np.zeros((h, w), bool)
+            img = bg + rs.normal(0, 10, size=(h, w))
+            img = np.where(inside, dark + rs.normal(0, 5, size=(h, w)), img)
+            frames.append(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+            gts.append(inside.astype(np.uint8) * 255)
+    return np.stack(frames), np.stack(gts)

@@ -1,0 +1,338 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Run in the build container only (``/root/reference`` does not exist on the GPU
+box)::
+
+    python tests/golden/gen_golden.py
+
+What is executed is the reference's own code, unmodified, imported from
+``/root/reference``: ``openglottal.models.unet.UNet`` (forward),
+``openglottal.utils.unet_segment_frame`` / ``dice`` / ``iou`` / ``dice_loss``,
+``openglottal.features._kinematic_features`` and
+``openglottal.models.detector.TemporalDetector.detect``.
+
+Three third-party modules the reference imports at module top are not
+installed here (cv2, torchvision, ultralytics).  None of their
+arithmetic is on the captured path, so empty placeholder modules are put in
+``sys.modules`` purely so that ``import openglottal`` succeeds:
+
+* ``cv2``: constants + ``resize`` that *asserts the requested size equals the
+  source size* and returns a copy (the identity `unet_segment_frame` performs
+  at 256×256, `utils.py:234,239`).  No other cv2 function is provided, so any
+  captured path that would need real OpenCV arithmetic fails loudly.
+* ``torchvision``: empty (only used by the training dataset class).
+* ``ultralytics.YOLO``: a *scripted fake* returning pre-programmed boxes, so
+  that the reference's temporal state machine (`detector.py:52-96`) runs
+  unmodified.  The YOLO network itself is third-party and absent → its
+  arithmetic is "parity unpinned" (SURVEY §8c).
+
+Outputs are data only (inputs are regenerated from seeds by
+``openglottal_amd.synth``): logits, bit-packed masks, integer areas, metric
+values, kinematic feature dicts, detector traces, and one tiny *trained*
+small-width checkpoint (weights are the product of running the reference's
+model + loss here; they are data, not source).
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+REF = "/root/reference"
+
+
+class ScriptedYOLO:
+    """Fake ``ultralytics.YOLO``: replays a per-call script of (xyxy, conf)."""
+
+    script: list = []  # class-level; set before constructing TemporalDetector
+
+    def __init__(self, path):
+        self.path = path
+        self.calls = 0
+
+    def __call__(self, frame, conf=0.25, verbose=False):
+        import torch
+
+        dets = ScriptedYOLO.script[self.calls]
+        self.calls += 1
+
+        class _Boxes:
+            def __init__(self, d):
+                d = [x for x in d if x[4] >= conf]
+                self.xyxy = torch.tensor([x[:4] for x in d], dtype=torch.float32).reshape(-1, 4)
+                self.conf = torch.tensor([x[4] for x in d], dtype=torch.float32)
+
+            def __len__(self):
+                return int(self.conf.shape[0])
+
+        class _Res:
+            pass
+
+        r = _Res()
+        r.boxes = _Boxes(dets)
+        return [r]
+
+
+def install_placeholders() -> None:
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_LINEAR, cv2.INTER_NEAREST, cv2.BORDER_CONSTANT, cv2.COLOR_BGR2GRAY = 1, 0, 0, 6
+
+    def resize(img, dsize, interpolation=None):
+        assert (img.shape[1], img.shape[0]) == tuple(dsize), "placeholder cv2.resize is identity-only"
+        return img.copy()
+
+    cv2.resize = resize
+    sys.modules["cv2"] = cv2
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvf = types.ModuleType("torchvision.transforms.functional")
+    tv.transforms, tvt.functional = tvt, tvf
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.transforms.functional": tvf})
+    ul = types.ModuleType("ultralytics")
+    ul.YOLO = ScriptedYOLO
+    sys.modules["ultralytics"] = ul
+    sys.path.insert(0, REF)
+
+
+def packbits(mask: np.ndarray) -> np.ndarray:
+    return np.packbits((mask > 0).astype(np.uint8).ravel())
+
+
+def main() -> None:
+    install_placeholders()
+    import torch
+
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+
+    import openglottal  # noqa: F401  (reference package)
+    from openglottal.features import _kinematic_features
+    from openglottal.models.detector import TemporalDetector
+    from openglottal.models.unet import UNet
+    from openglottal.utils import dice, dice_loss, iou, unet_segment_frame
+
+    from openglottal_amd import synth
+
+    dev = torch.device("cpu")
+    meta: dict = {"torch": torch.__version__, "numpy": np.__version__, "threads": torch.get_num_threads()}
+
+    # ── (1) full-width U-Net, seeded weights, calibrated head ────────────────
+    feats = (32, 64, 128, 256)
+    seed = 20260227
+    noise = synth.random_gray_frames(4, seed=7)
+    glot, glot_gt = synth.glottis_frames(1, 4, seed=99)
+    frames = np.concatenate([noise, glot], axis=0)  # [8,256,256]
+
+    sd0 = synth.make_unet_state_dict(feats, seed=seed)
+    model = UNet(1, 1, feats)
+    model.load_state_dict(synth.state_dict_to_torch(sd0))
+    model.eval()
+    with torch.no_grad():
+        x = torch.from_numpy(frames.astype("float32") / 255.0).unsqueeze(1)
+        raw = model(x).numpy()
+    hb0 = float(sd0["head.bias"][0])
+    lin = raw - hb0
+    head_scale = float(2.0 / lin.std())
+    head_bias = float(-np.quantile(head_scale * lin, 0.82))
+    sd = synth.make_unet_state_dict(feats, seed=seed, head_scale=head_scale, head_bias=head_bias)
+    model.load_state_dict(synth.state_dict_to_torch(sd))
+    model.eval()
+    with torch.no_grad():
+        logits = model(x).numpy()[:, 0]  # [8,256,256]
+    masks = np.stack([unet_segment_frame(f, model, dev) for f in frames])
+    areas = np.array([int(np.sum(m > 0)) for m in masks], dtype=np.int64)
+    assert np.array_equal(masks > 0, logits > 0), "sigmoid>0.5 vs logit>0 disagree on reference output"
+    samp = np.random.RandomState(5).choice(256 * 256, size=4096, replace=False).astype(np.int32)
+    np.savez_compressed(
+        os.path.join(HERE, "unet_full.npz"),
+        features=np.array(feats),
+        seed=seed,
+        head_scale=head_scale,
+        head_bias=head_bias,
+        logits_full=logits[[0, 4]].astype(np.float32),  # frame 0 (noise) and 4 (glottis)
+        sample_idx=samp,
+        logits_samples=logits.reshape(8, -1)[:, samp].astype(np.float32),
+        masks_packed=np.stack([packbits(m) for m in masks]),
+        areas=areas,
+        abs_logit_min=np.abs(logits).reshape(8, -1).min(axis=1),
+        n_abs_logit_lt_1e3=(np.abs(logits) < 1e-3).reshape(8, -1).sum(axis=1),
+        dice_vs_gt=np.array([dice(masks[4 + i], glot_gt[i]) for i in range(4)]),
+        iou_vs_gt=np.array([iou(masks[4 + i], glot_gt[i]) for i in range(4)]),
+    )
+    meta["unet_full"] = {"areas": areas.tolist(), "head_scale": head_scale, "head_bias": head_bias,
+                         "abs_logit_min": np.abs(logits).reshape(8, -1).min(axis=1).tolist()}
+    print("full:", areas, "min|logit|", np.abs(logits).min())
+
+    # ── (2) small-width net: every layer-boundary tensor, two sizes ──────────
+    sfeats = (4, 8, 16, 32)
+    ssd = synth.make_unet_state_dict(sfeats, seed=11, head_scale=3.0, head_bias=-0.4)
+    sm = UNet(1, 1, sfeats)
+    sm.load_state_dict(synth.state_dict_to_torch(ssd))
+    sm.eval()
+    caps: dict[str, np.ndarray] = {}
+    pool_n = [0]
+
+    def hook(name):
+        def _h(mod, inp, out):
+            caps[name] = out.detach().numpy().copy()
+        return _h
+
+    def pool_hook(mod, inp, out):
+        caps[f"pool{pool_n[0]}"] = out.detach().numpy().copy()
+        pool_n[0] += 1
+
+    hs = []
+    for i, d in enumerate(sm.downs):
+        hs.append(d.net[2].register_forward_hook(hook(f"downs.{i}.a")))
+        hs.append(d.net[5].register_forward_hook(hook(f"downs.{i}.b")))
+    hs.append(sm.bottleneck.net[2].register_forward_hook(hook("bottleneck.a")))
+    hs.append(sm.bottleneck.net[5].register_forward_hook(hook("bottleneck.b")))
+    for j in range(0, 8, 2):
+        hs.append(sm.ups[j].register_forward_hook(hook(f"ups.{j}")))
+        hs.append(sm.ups[j + 1].net[2].register_forward_hook(hook(f"ups.{j + 1}.a")))
+        hs.append(sm.ups[j + 1].net[5].register_forward_hook(hook(f"ups.{j + 1}.b")))
+    hs.append(sm.head.register_forward_hook(hook("head")))
+    hs.append(sm.pool.register_forward_hook(pool_hook))
+    f64 = synth.random_gray_frames(1, 64, 64, seed=21)
+    with torch.no_grad():
+        sm(torch.from_numpy(f64.astype("float32") / 255.0).unsqueeze(1))
+    for h_ in hs:
+        h_.remove()
+    out = {f"L:{k}": v.astype(np.float32) for k, v in caps.items()}
+    fr = synth.random_gray_frames(3, 48, 80, seed=22)  # non-square, H,W % 16 == 0, batch 3
+    with torch.no_grad():
+        out["logits_48x80"] = sm(torch.from_numpy(fr.astype("float32") / 255.0).unsqueeze(1)).numpy()
+    np.savez_compressed(os.path.join(HERE, "unet_small_layers.npz"), features=np.array(sfeats), seed=11,
+                        head_scale=3.0, head_bias=-0.4, **out)
+    print("small layers:", len(caps), "tensors")
+
+    # ── (3) tiny TRAINED net on structured frames (realistic logit margins) ──
+    torch.manual_seed(1)
+    tm = UNet(1, 1, sfeats)
+    opt = torch.optim.AdamW(tm.parameters(), lr=3e-3)
+    tr_x, tr_y = synth.glottis_frames(12, 20, seed=1001)
+    tx = torch.from_numpy(tr_x.astype("float32") / 255.0).unsqueeze(1)
+    ty = torch.from_numpy((tr_y > 0).astype("float32")).unsqueeze(1)
+    tm.train()
+    g = torch.Generator().manual_seed(3)
+    for step in range(400):
+        idx = torch.randint(0, tx.shape[0], (8,), generator=g)
+        lo = tm(tx[idx])
+        # reference recipe: 0.5 BCE + 0.5 Dice (`scripts/train_unet.py:155-157`)
+        loss = 0.5 * torch.nn.functional.binary_cross_entropy_with_logits(lo, ty[idx]) + 0.5 * dice_loss(lo, ty[idx])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if step % 100 == 0:
+            print("  train step", step, float(loss))
+    tm.eval()
+    ev_x, ev_y = synth.glottis_frames(4, 20, seed=99)  # the 80-frame GIRAFE stand-in
+    ev_masks = np.stack([unet_segment_frame(f, tm, dev) for f in ev_x])
+    with torch.no_grad():
+        ev_logits = tm(torch.from_numpy(ev_x.astype("float32") / 255.0).unsqueeze(1)).numpy()[:, 0]
+    ev_areas = np.array([int(np.sum(m > 0)) for m in ev_masks], dtype=np.int64)
+    ev_dice = np.array([dice(m, g_) for m, g_ in zip(ev_masks, ev_y)])
+    ev_iou = np.array([iou(m, g_) for m, g_ in zip(ev_masks, ev_y)])
+    tsd = {k: v.detach().numpy() for k, v in tm.state_dict().items()}
+    np.savez_compressed(
+        os.path.join(HERE, "unet_trained_small.npz"),
+        features=np.array(sfeats),
+        **{"W:" + k: v for k, v in tsd.items()},
+        masks_packed=np.stack([packbits(m) for m in ev_masks]),
+        areas=ev_areas,
+        dice_vs_gt=ev_dice,
+        iou_vs_gt=ev_iou,
+        abs_logit_min=np.abs(ev_logits).reshape(80, -1).min(axis=1),
+        n_abs_logit_lt_1e3=(np.abs(ev_logits) < 1e-3).reshape(80, -1).sum(axis=1),
+        logits_row128=ev_logits[:, 128, :].astype(np.float32),
+    )
+    print("trained small: mean dice", ev_dice.mean(), "areas", ev_areas[:10], "n|logit|<1e-3:",
+          int((np.abs(ev_logits) < 1e-3).sum()))
+    meta["trained_small"] = {"mean_dice": float(ev_dice.mean()), "mean_iou": float(ev_iou.mean())}
+
+    # ── (4) kinematic features (`features.py:38-68`) ──────────────────────────
+    kin_cases = {}
+    t = np.arange(120)
+    waves = {
+        "periodic": np.rint(400 + 300 * np.sin(2 * np.pi * t / 12.0)).clip(0).tolist(),
+        "slow_f0_none": np.rint(400 + 300 * np.sin(2 * np.pi * t / 120.0)).clip(0).tolist(),
+        "silent": [0.0] * 40,
+        "short": [5.0, 0.0, 7.0],
+        "areas_trained": [float(a) for a in ev_areas],
+        "noisy": np.random.RandomState(8).randint(0, 900, 77).astype(float).tolist(),
+    }
+    for name, w in waves.items():
+        r = _kinematic_features(list(w))
+        if r is None:
+            kin_cases[name] = {"wave": w, "out": None}
+        else:
+            kin_cases[name] = {"wave": w, "out": {k: (None if v is None else float(v)) for k, v in r.items() if k != "_area"}}
+    with open(os.path.join(HERE, "kinematic.json"), "w") as f:
+        json.dump(kin_cases, f)
+
+    # ── (5) TemporalDetector state machine traces (`detector.py:52-96`) ──────
+    def run_trace(script, shape=(256, 256, 3), **kw):
+        ScriptedYOLO.script = script
+        det = TemporalDetector("fake.pt", **kw)
+        frame = np.zeros(shape, np.uint8)
+        outs = []
+        for _ in script:
+            b = det.detect(frame)
+            outs.append(None if b is None else [int(v) for v in b])
+        return outs
+
+    hit = [100.3, 90.7, 140.9, 170.2, 0.9]
+    traces = {}
+    scripts = {
+        "hit_then_misses": [[hit]] + [[]] * 5 + [[hit]],
+        "jump_rejected": [[hit], [[180.0, 170.0, 220.0, 250.0, 0.8]], [[101.0, 91.0, 142.0, 172.9, 0.7]]],
+        "no_det_first": [[], [], [hit]],
+        "edge_clamp": [[[1.0, 2.0, 30.5, 40.5, 0.9]], [[230.0, 220.0, 255.0, 255.9, 0.9]]],
+        "multi_box_argmax": [[[10, 10, 50, 50, 0.3], [100, 100, 150, 160, 0.95], [60, 60, 90, 90, 0.5]]],
+        "below_conf": [[[100, 100, 150, 160, 0.2]], [hit]],
+        "jump_x4_then_reacquire": [[hit]] + [[[200.0, 200.0, 240.0, 250.0, 0.9]]] * 5,
+    }
+    rsx = np.random.RandomState(17)
+    rnd = []
+    cx, cy = 128.0, 128.0
+    for _ in range(200):
+        if rsx.rand() < 0.25:
+            rnd.append([])
+            continue
+        if rsx.rand() < 0.1:
+            cx, cy = rsx.uniform(20, 236, 2)
+        cx += rsx.uniform(-12, 12)
+        cy += rsx.uniform(-12, 12)
+        w_, h_ = rsx.uniform(10, 80, 2)
+        rnd.append([[float(cx - w_ / 2), float(cy - h_ / 2), float(cx + w_ / 2), float(cy + h_ / 2), float(rsx.uniform(0.1, 1.0))]])
+    scripts["random_200"] = rnd
+    for name, sc in scripts.items():
+        traces[name] = {"script": sc, "shape": [256, 256, 3], "kw": {}, "out": run_trace(sc)}
+    traces["custom_params"] = {"script": scripts["random_200"], "shape": [208, 352, 3],
+                               "kw": dict(conf=0.5, max_shift_px=15, padding=4, max_hold_frames=1),
+                               "out": run_trace(scripts["random_200"], (208, 352, 3), conf=0.5, max_shift_px=15,
+                                                padding=4, max_hold_frames=1)}
+    with open(os.path.join(HERE, "detector_traces.json"), "w") as f:
+        json.dump(traces, f)
+
+    # ── (6) gated area (`features.py:240-245`) on the trained net's masks ────
+    boxes = [[100, 80, 160, 200], [0, 0, 256, 256], [120, 120, 121, 121], [30, 40, 30, 90]]
+    gated = [[int(np.sum(ev_masks[i][b[1]:b[3], b[0]:b[2]] > 0)) for b in boxes] for i in range(8)]
+    meta["gated"] = {"boxes": boxes, "areas_first8": gated}
+
+    with open(os.path.join(HERE, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
