@@ -1,0 +1,124 @@
+/*
+ * openglottal_hip.h — C-ABI of the MI355X-native glottal segmentation hot path.
+ *
+ * The reference (hari-krishnan/openglottal) is pure Python and has no FFI; the
+ * "plugin/operator API" for this path is the Python call surface of
+ *   openglottal/models/unet.py:36-88      UNet(in_ch,out_ch,features), .load_state_dict, __call__
+ *   openglottal/utils.py:218-241          unet_segment_frame(frame_gray, model, device, threshold)
+ *   openglottal/features.py:234-245       per-frame area = sum(mask>0) [inside the YOLO box]
+ *   scripts/benchmark_video_speed.py:89-109  timed frame loop
+ * Each entry point below names the reference lines it replaces.  A maintainer
+ * binds them with ctypes/cffi (INTEGRATION.md shows the stub); the in-tree host
+ * mirror (openglottal_amd/unet.py, utils.py, features.py) does exactly that.
+ *
+ * Conventions
+ *  - every call returns 0 on success or a negative OG_E* code; nothing throws
+ *    or aborts across the ABI; og_last_error() returns a thread-local string.
+ *  - host buffers are caller-owned and only read/written during the call.
+ *  - *_dev entry points take DEVICE pointers (hipMalloc'd or a torch tensor's
+ *    data_ptr()), enqueue on the handle's stream and return without syncing;
+ *    call og_unet_sync() before reading results.
+ *  - a handle is not thread-safe; distinct handles are independent.
+ *  - tensors are plain C arrays: NCHW float32 for og_unet_forward_f32 (as the
+ *    reference's torch tensors), [B,H,W] uint8 for frames and masks.
+ */
+#ifndef OPENGLOTTAL_HIP_H
+#define OPENGLOTTAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OG_OK 0
+#define OG_EINVAL (-1)   /* bad argument / shape / key */
+#define OG_ESTATE (-2)   /* call order (e.g. forward before finalize) */
+#define OG_EHIP (-3)     /* HIP runtime error, see og_last_error() */
+#define OG_ENOMEM (-4)
+#define OG_ENODEV (-5)   /* no usable gfx950 device */
+
+#define OG_DTYPE_F32 0
+#define OG_DTYPE_I64 1
+
+typedef struct og_unet og_unet;
+
+/* Library / device ------------------------------------------------------- */
+const char* og_last_error(void);
+const char* og_version(void);
+int og_device_count(void);                 /* >=0, or negative error */
+int og_init(int device);                   /* select device (replaces torch.device(...), cli.py:56) */
+
+/* Device memory helpers (plumbing for callers without torch) -------------- */
+void* og_malloc(size_t bytes);             /* NULL on failure */
+int og_free(void* dptr);
+int og_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int og_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+
+/* U-Net handle ------------------------------------------------------------ */
+/* = UNet.__init__ (unet.py:50-72).  features[n_levels]; in_ch and out_ch must be 1
+ * (the only configuration the reference's pipelines construct, cli.py:61). */
+og_unet* og_unet_create(const int* features, int n_levels, int in_ch, int out_ch);
+void og_unet_destroy(og_unet* h);
+
+/* = load_state_dict, one tensor per call (cli.py:62-64).  The library COPIES.
+ * key: reference state_dict key, e.g. "downs.0.net.0.weight".  Unknown key or
+ * wrong shape -> OG_EINVAL.  "*.num_batches_tracked" (int64) accepted, ignored. */
+int og_unet_set_tensor(og_unet* h, const char* key, const void* host, const int64_t* shape, int ndim, int dtype);
+
+/* Strict completeness check, BatchNorm fold (eval mode, eps 1e-5, in float64),
+ * repack into the kernels' MFMA fragment layout, upload.  = .eval().to(device) */
+int og_unet_finalize(og_unet* h);
+
+/* = UNet.forward (unet.py:74-88): x [B,1,H,W] f32 (host) -> logits [B,1,H,W] f32 (host).
+ * H and W must be multiples of 2^n_levels (the reference's bilinear fallback,
+ * unet.py:84-85, never fires there).  Synchronous. */
+int og_unet_forward_f32(og_unet* h, const float* x_nchw, int B, int H, int W, float* logits_nchw);
+
+/* = unet_segment_frame (utils.py:218-241) over a batch of frames already at
+ * network resolution, fused with the area count of features.py:238 / :241-245.
+ *   gray   [B,H,W] u8              (required)
+ *   boxes  [B,4] int32 x1,y1,x2,y2 or NULL; x1<0 marks "no detection" -> area 0
+ *   mask   [B,H,W] u8 in {0,255}   or NULL
+ *   area   [B] int32               or NULL   (count of mask>0, inside box if given)
+ *   logits [B,H,W] f32             or NULL   (debug / parity)
+ * Host-pointer variant is synchronous (H2D, run, D2H). */
+int og_unet_segment_u8(og_unet* h, const uint8_t* gray, int B, int H, int W, float threshold,
+                       const int32_t* boxes, uint8_t* mask, int32_t* area, float* logits);
+/* Same, DEVICE pointers, asynchronous on the handle's stream. */
+int og_unet_segment_u8_dev(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, float threshold,
+                           const int32_t* boxes_dev, uint8_t* mask_dev, int32_t* area_dev, float* logits_dev);
+
+/* Box-gated recount on masks already on the device (features.py:244-245 when the
+ * boxes only become known after the sequential TemporalDetector pass). */
+int og_mask_area_dev(og_unet* h, const uint8_t* mask_dev, int B, int H, int W, const int32_t* boxes_dev, int32_t* area_dev);
+
+/* = cv2.cvtColor(frame, COLOR_BGR2GRAY) (features.py:235) for [B,H,W,3] u8 on the device. */
+int og_bgr2gray_dev(og_unet* h, const uint8_t* bgr_dev, int B, int H, int W, uint8_t* gray_dev);
+
+int og_unet_sync(og_unet* h);
+void* og_unet_stream(og_unet* h);          /* hipStream_t the handle launches on */
+
+/* Micro-batch the frame loop uses per kernel chain (default 16); >=1. */
+int og_unet_set_chunk(og_unet* h, int frames_per_launch);
+/* 1 = replay captured hipGraphs for repeated shapes (default), 0 = eager launches. */
+int og_unet_set_graphs(og_unet* h, int enable);
+
+/* HIP-event timing on the handle's stream (bench.py's roofline leg). */
+int og_timer_start(og_unet* h);
+int og_timer_stop(og_unet* h, float* elapsed_ms);   /* records, synchronises, returns ms since start */
+
+/* Parity/debug: copy a layer-boundary activation of the LAST forward/segment call
+ * (first `B` frames of the last chunk) to host as NCHW f32.  Names follow
+ * tests/golden: "downs.0.a", "downs.0.b", "pool0", "bottleneck.a", "ups.0", "ups.1.a", ...
+ * Writes C,H,W into dims[3]; returns OG_EINVAL if capacity_floats is too small. */
+int og_unet_get_activation(og_unet* h, const char* name, int B, float* out_nchw, size_t capacity_floats, int* dims);
+
+/* Algorithmic work of one forward at HxW (conv + convT + head MACs x2), for rooflines. */
+double og_unet_flops_per_frame(og_unet* h, int H, int W);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENGLOTTAL_HIP_H */

@@ -1,0 +1,859 @@
+// C-ABI host side of libopenglottal_hip.so: state_dict intake, BN fold, weight
+// repack into the MFMA fragment/LDS image, activation arena, kernel chain,
+// hipGraph replay.  See include/openglottal_hip.h for the contract.
+#include "../../include/openglottal_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "og_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            return fail(OG_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+        }                                                                                     \
+    } while (0)
+
+inline int cp32(int c) { return (c + 31) / 32 * 32; }
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct ConvLayer {  // one 3x3 conv + BN + ReLU, or one 2x2 transposed conv
+    std::string name;
+    int mode = 0;  // 0 conv3x3, 1 convT
+    int Cin = 0, Cout = 0;      // true channel counts (for FLOP accounting)
+    int Cin_p = 0, Cout_p = 0;  // padded (buffer) channel counts
+    int NT = 1;
+    float* d_w = nullptr;
+    float* d_scale = nullptr;
+    float* d_shift = nullptr;
+};
+
+struct Act {  // NHWC activation view
+    float* p = nullptr;
+    int C = 0;  // pixel stride (floats)
+    int H = 0, W = 0;
+    long long frame_stride() const { return (long long)H * W * C; }
+};
+
+struct GraphKey {
+    int B, H, W;
+    bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
+};
+
+}  // namespace
+
+struct og_unet {
+    std::vector<int> features;
+    int L = 0;
+    std::map<std::string, HostTensor> host;
+    std::map<std::string, std::vector<int64_t>> expected;
+    bool finalized = false;
+
+    // parameters on device
+    float* d_first_w = nullptr;  // [9][Cp0]
+    float* d_first_scale = nullptr;
+    float* d_first_shift = nullptr;
+    std::vector<ConvLayer> enc_a, enc_b;  // enc_a[0] unused (first layer is k_conv_first)
+    ConvLayer bott_a, bott_b;
+    std::vector<ConvLayer> up_t, dec_a, dec_b;  // indexed by j (0 = deepest)
+    float* d_head_w = nullptr;
+    float head_bias = 0.f;
+    float* d_zero = nullptr;
+
+    // activation arena for (capB, H, W)
+    int capB = 0, aH = 0, aW = 0;
+    void* arena = nullptr;
+    std::vector<Act> A, CAT, P, UA, UB;
+    Act BA, BB;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int chunk = 16;
+    int use_graphs = 1;
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    int lastB = 0;
+
+    // staging for host-pointer entry points
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+};
+
+namespace {
+
+void expect(og_unet* h, const std::string& k, std::vector<int64_t> s) { h->expected[k] = std::move(s); }
+
+void expect_double_conv(og_unet* h, const std::string& p, int ci, int co) {
+    expect(h, p + ".net.0.weight", {co, ci, 3, 3});
+    expect(h, p + ".net.3.weight", {co, co, 3, 3});
+    for (const char* n : {".net.1", ".net.4"}) {
+        for (const char* f : {".weight", ".bias", ".running_mean", ".running_var"}) expect(h, p + n + f, {co});
+    }
+}
+
+// Fold eval-mode BatchNorm2d (eps 1e-5) into y = conv*scale + shift, in float64.
+void fold_bn(const og_unet* h, const std::string& bn, int C, int Cp, std::vector<float>& scale, std::vector<float>& shift) {
+    const auto& g = h->host.at(bn + ".weight").data;
+    const auto& b = h->host.at(bn + ".bias").data;
+    const auto& mu = h->host.at(bn + ".running_mean").data;
+    const auto& var = h->host.at(bn + ".running_var").data;
+    scale.assign(Cp, 0.f);
+    shift.assign(Cp, 0.f);
+    for (int c = 0; c < C; ++c) {
+        const double s = (double)g[c] / std::sqrt((double)var[c] + 1e-5);
+        scale[c] = (float)s;
+        shift[c] = (float)((double)b[c] - (double)mu[c] * s);
+    }
+}
+
+// Packed weight image, consumed verbatim by LDS-DMA (global_load_lds writes LDS
+// linearly, so the bank swizzle lives in this global layout):
+//   [n_tile][chunk][tap][row r in 0..32*NT)[8 slots of 4 floats], slot' = slot ^ ((r>>1)&7)
+// row r <-> GEMM column n = n_tile*32*NT + r; slot/element <-> padded input channel k.
+template <typename F>
+std::vector<float> pack_gemm_b(int Ncols_p, int Kp, int taps, int NT, F&& weight_at /*(n, k, tap)->float*/) {
+    const int rows = 32 * NT;
+    const int n_tiles = Ncols_p / rows;
+    const int n_chunks = Kp / 32;
+    std::vector<float> out((size_t)Ncols_p * Kp * taps, 0.f);
+    size_t o = 0;
+    for (int nt = 0; nt < n_tiles; ++nt)
+        for (int c = 0; c < n_chunks; ++c)
+            for (int t = 0; t < taps; ++t) {
+                for (int r = 0; r < rows; ++r)
+                    for (int ps = 0; ps < 8; ++ps) {
+                        const int sl = ps ^ ((r >> 1) & 7);
+                        for (int e = 0; e < 4; ++e) out[o + (size_t)r * 32 + ps * 4 + e] = weight_at(nt * rows + r, c * 32 + sl * 4 + e, t);
+                    }
+                o += (size_t)rows * 32;
+            }
+    return out;
+}
+
+int upload(const std::vector<float>& v, float** d) {
+    HIPCHK(hipMalloc((void**)d, v.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(*d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return OG_OK;
+}
+
+// cin_map: padded input channel -> original input channel (or -1)
+int build_conv(og_unet* h, ConvLayer& L, const std::string& wkey, const std::string& bnkey, int Cin, int Cout,
+               const std::vector<int>& cin_map) {
+    L.name = wkey;
+    L.mode = 0;
+    L.Cin = Cin;
+    L.Cout = Cout;
+    L.Cin_p = (int)cin_map.size();
+    L.Cout_p = cp32(Cout);
+    L.NT = (L.Cout_p % 64 == 0) ? 2 : 1;
+    const auto& w = h->host.at(wkey).data;  // [Cout][Cin][3][3]
+    auto at = [&](int n, int k, int t) -> float {
+        const int ci = cin_map[k];
+        if (n >= Cout || ci < 0) return 0.f;
+        return w[((size_t)n * Cin + ci) * 9 + t];
+    };
+    std::vector<float> pk = pack_gemm_b(L.Cout_p, L.Cin_p, 9, L.NT, at);
+    std::vector<float> sc, sh;
+    fold_bn(h, bnkey, Cout, L.Cout_p, sc, sh);
+    int rc;
+    if ((rc = upload(pk, &L.d_w))) return rc;
+    if ((rc = upload(sc, &L.d_scale))) return rc;
+    if ((rc = upload(sh, &L.d_shift))) return rc;
+    return OG_OK;
+}
+
+int build_convT(og_unet* h, ConvLayer& L, const std::string& p, int Cin, int Cout) {
+    L.name = p;
+    L.mode = 1;
+    L.Cin = Cin;
+    L.Cout = Cout;
+    L.Cin_p = cp32(Cin);
+    L.Cout_p = cp32(Cout);
+    L.NT = 2;  // N = 4*Cout_p is a multiple of 128
+    const auto& w = h->host.at(p + ".weight").data;  // [Cin][Cout][2][2]
+    const auto& bias = h->host.at(p + ".bias").data;
+    const int Cop = L.Cout_p;
+    auto at = [&](int n, int k, int) -> float {
+        const int q = n / Cop, co = n % Cop;
+        if (co >= Cout || k >= Cin) return 0.f;
+        return w[((size_t)k * Cout + co) * 4 + q];
+    };
+    std::vector<float> pk = pack_gemm_b(4 * Cop, L.Cin_p, 1, L.NT, at);
+    std::vector<float> sc(Cop, 0.f), sh(Cop, 0.f);
+    for (int c = 0; c < Cout; ++c) {
+        sc[c] = 1.f;
+        sh[c] = bias[c];
+    }
+    int rc;
+    if ((rc = upload(pk, &L.d_w))) return rc;
+    if ((rc = upload(sc, &L.d_scale))) return rc;
+    if ((rc = upload(sh, &L.d_shift))) return rc;
+    return OG_OK;
+}
+
+std::vector<int> ident_map(int Cin) {
+    std::vector<int> m(cp32(Cin), -1);
+    for (int i = 0; i < Cin; ++i) m[i] = i;
+    return m;
+}
+
+void free_layer(ConvLayer& L) {
+    if (L.d_w) (void)hipFree(L.d_w);
+    if (L.d_scale) (void)hipFree(L.d_scale);
+    if (L.d_shift) (void)hipFree(L.d_shift);
+    L.d_w = L.d_scale = L.d_shift = nullptr;
+}
+
+void drop_graphs(og_unet* h) {
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
+}
+
+int ensure_arena(og_unet* h, int B, int H, int W) {
+    if (h->arena && B <= h->capB && H == h->aH && W == h->aW) return OG_OK;
+    drop_graphs(h);
+    if (h->arena) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipFree(h->arena));
+        h->arena = nullptr;
+    }
+    const int L = h->L;
+    h->A.assign(L, Act());
+    h->CAT.assign(L, Act());
+    h->P.assign(L, Act());
+    h->UA.assign(L, Act());
+    h->UB.assign(L, Act());
+    size_t total = 0;
+    auto plan = [&](Act& a, int C, int hh, int ww) {
+        a.C = C;
+        a.H = hh;
+        a.W = ww;
+        a.p = (float*)total;  // offset for now
+        total += ((size_t)B * hh * ww * C * sizeof(float) + 255) / 256 * 256;
+    };
+    for (int i = 0; i < L; ++i) {
+        const int C = cp32(h->features[i]);
+        const int hh = H >> i, ww = W >> i;
+        plan(h->A[i], C, hh, ww);
+        plan(h->CAT[i], 2 * C, hh, ww);
+        plan(h->P[i], C, hh >> 1, ww >> 1);
+        plan(h->UA[i], C, hh, ww);
+        plan(h->UB[i], C, hh, ww);
+    }
+    const int Cb = cp32(2 * h->features[L - 1]);
+    plan(h->BA, Cb, H >> L, W >> L);
+    plan(h->BB, Cb, H >> L, W >> L);
+    HIPCHK(hipMalloc(&h->arena, total));
+    // Padded channels of the convT half etc. are always written (zero weights ->
+    // exact zeros), but clear once so debug reads of never-touched bytes are defined.
+    HIPCHK(hipMemsetAsync(h->arena, 0, total, h->stream));
+    auto fix = [&](Act& a) { a.p = (float*)((char*)h->arena + (size_t)a.p); };
+    for (int i = 0; i < L; ++i) {
+        fix(h->A[i]);
+        fix(h->CAT[i]);
+        fix(h->P[i]);
+        fix(h->UA[i]);
+        fix(h->UB[i]);
+    }
+    fix(h->BA);
+    fix(h->BB);
+    h->capB = B;
+    h->aH = H;
+    h->aW = W;
+    return OG_OK;
+}
+
+template <int NT, int MODE, int TH>
+int launch_conv_t(og_unet* h, const ConvArgs& a, int n_ntiles) {
+    constexpr int PAD = (MODE == 0) ? 1 : 0;
+    constexpr int lds = 2 * (16 + 2 * PAD) * (TH + 2 * PAD) * 128 + 2 * 32 * NT * 128;
+    const unsigned grid = (unsigned)(a.n_spatial * n_ntiles);
+    hipLaunchKernelGGL((k_conv_mfma<NT, MODE, TH>), dim3(grid), dim3(256), lds, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return OG_OK;
+}
+
+template <int NT, int MODE, int TH>
+int set_conv_attr() {
+    constexpr int PAD = (MODE == 0) ? 1 : 0;
+    constexpr int lds = 2 * (16 + 2 * PAD) * (TH + 2 * PAD) * 128 + 2 * 32 * NT * 128;
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma<NT, MODE, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    return OG_OK;
+}
+
+int init_kernel_attrs() {  // must not run inside a stream capture
+    int rc;
+    if ((rc = set_conv_attr<2, 0, 8>())) return rc;
+    if ((rc = set_conv_attr<1, 0, 8>())) return rc;
+    if ((rc = set_conv_attr<2, 1, 8>())) return rc;
+    return OG_OK;
+}
+
+// in: activation view + channel offset/count; out likewise; pool optional
+int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off, const Act& out, int out_off, const Act* pool) {
+    constexpr int TH = 8;
+    ConvArgs a;
+    a.in = in.p;
+    a.in_frame_stride = in.frame_stride();
+    a.in_pix_stride = in.C;
+    a.in_ch_off = in_off;
+    a.n_chunks = L.Cin_p / 32;
+    a.H = in.H;
+    a.W = in.W;
+    a.tiles_x = (in.W + 15) / 16;
+    a.tiles_y = (in.H + TH - 1) / TH;
+    a.n_spatial = B * a.tiles_x * a.tiles_y;
+    a.wpk = L.d_w;
+    a.scale = L.d_scale;
+    a.shift = L.d_shift;
+    a.aff_mod = L.Cout_p;
+    a.out = out.p;
+    a.out_frame_stride = out.frame_stride();
+    a.out_pix_stride = out.C;
+    a.out_ch_off = out_off;
+    a.pool = pool ? pool->p : nullptr;
+    a.pool_frame_stride = pool ? pool->frame_stride() : 0;
+    a.pool_pix_stride = pool ? pool->C : 0;
+    a.pool_ch_off = 0;
+    a.zero_page = h->d_zero;
+    a.relu = (L.mode == 0) ? 1 : 0;
+    if (L.mode == 0) {
+        const int n_ntiles = L.Cout_p / (32 * L.NT);
+        if (out.H != in.H || out.W != in.W) return fail(OG_EINVAL, "conv shape mismatch");
+        return (L.NT == 2) ? launch_conv_t<2, 0, TH>(h, a, n_ntiles) : launch_conv_t<1, 0, TH>(h, a, n_ntiles);
+    }
+    if (out.H != 2 * in.H || out.W != 2 * in.W) return fail(OG_EINVAL, "convT shape mismatch");
+    return launch_conv_t<2, 1, TH>(h, a, 4 * L.Cout_p / 64);
+}
+
+enum { KIND_U8 = 0, KIND_F32 = 1 };
+
+// The chain is: k_conv_first (reads the caller's frames) -> body (arena only) -> k_head
+// (writes the caller's outputs).  Only the body is pointer-stable, so only the body is
+// captured into a hipGraph (keyed by B,H,W); first and head are plain launches around it.
+int enqueue_first(og_unet* h, int kind, const void* in, int B, int H, int W) {
+    const int Cp0 = cp32(h->features[0]);
+    const int tiles = ((W + 15) / 16) * ((H + 15) / 16);
+    const Act& o = h->A[0];
+    if (kind == KIND_U8)
+        hipLaunchKernelGGL(k_conv_first<uint8_t>, dim3(B * tiles), dim3(256), 0, h->stream, (const uint8_t*)in, o.p,
+                           h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride());
+    else
+        hipLaunchKernelGGL(k_conv_first<float>, dim3(B * tiles), dim3(256), 0, h->stream, (const float*)in, o.p,
+                           h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride());
+    HIPCHK(hipGetLastError());
+    return OG_OK;
+}
+
+int enqueue_body(og_unet* h, int B) {
+    const int L = h->L;
+    int rc;
+    for (int i = 0; i < L; ++i) {
+        if (i > 0 && (rc = launch_conv(h, h->enc_a[i], B, h->P[i - 1], 0, h->A[i], 0, nullptr))) return rc;
+        if ((rc = launch_conv(h, h->enc_b[i], B, h->A[i], 0, h->CAT[i], 0, &h->P[i]))) return rc;
+    }
+    if ((rc = launch_conv(h, h->bott_a, B, h->P[L - 1], 0, h->BA, 0, nullptr))) return rc;
+    if ((rc = launch_conv(h, h->bott_b, B, h->BA, 0, h->BB, 0, nullptr))) return rc;
+    for (int j = 0; j < L; ++j) {
+        const int i = L - 1 - j;
+        const Act& src = (j == 0) ? h->BB : h->UB[i + 1];
+        const int Ci = cp32(h->features[i]);
+        if ((rc = launch_conv(h, h->up_t[j], B, src, 0, h->CAT[i], Ci, nullptr))) return rc;
+        if ((rc = launch_conv(h, h->dec_a[j], B, h->CAT[i], 0, h->UA[i], 0, nullptr))) return rc;
+        if ((rc = launch_conv(h, h->dec_b[j], B, h->UA[i], 0, h->UB[i], 0, nullptr))) return rc;
+    }
+    return OG_OK;
+}
+
+int enqueue_head(og_unet* h, int B, int H, int W, float thr, const int32_t* boxes, uint8_t* mask, int32_t* area, float* logits) {
+    const Act& u = h->UB[0];
+    const int HW = H * W;
+    const int bpf = (HW + 1023) / 1024;
+    hipLaunchKernelGGL(k_head, dim3(B * bpf), dim3(256), 0, h->stream, u.p, u.frame_stride(), u.C, h->d_head_w,
+                       h->head_bias, cp32(h->features[0]), HW, W, thr, boxes, logits, mask, area, bpf);
+    HIPCHK(hipGetLastError());
+    return OG_OK;
+}
+
+// One chunk of B (<= capB) frames.  Body eager, or replayed from a cached hipGraph
+// (launch-bound at small B otherwise: 5*L+2 launches, MI355X_MICROARCH.md "graph-replay-floor").
+int run_chunk(og_unet* h, int kind, const void* in, int B, int H, int W, float thr, const int32_t* boxes, uint8_t* mask,
+              int32_t* area, float* logits) {
+    h->lastB = B;
+    int rc;
+    if ((rc = enqueue_first(h, kind, in, B, H, W))) return rc;
+    if (!h->use_graphs) {
+        if ((rc = enqueue_body(h, B))) return rc;
+    } else {
+        GraphKey key;
+        memset(&key, 0, sizeof(key));
+        key.B = B;
+        key.H = H;
+        key.W = W;
+        auto it = h->graphs.find(key);
+        if (it == h->graphs.end()) {
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_body(h, B);
+            hipError_t e = hipStreamEndCapture(h->stream, &g);
+            if (rc) {
+                if (g) (void)hipGraphDestroy(g);
+                return rc;
+            }
+            if (e != hipSuccess) return fail(OG_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            hipGraphExec_t ge = nullptr;
+            e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) return fail(OG_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+            it = h->graphs.emplace(key, ge).first;
+        }
+        HIPCHK(hipGraphLaunch(it->second, h->stream));
+    }
+    return enqueue_head(h, B, H, W, thr, boxes, mask, area, logits);
+}
+
+int check_shape(og_unet* h, int B, int H, int W) {
+    if (!h) return fail(OG_EINVAL, "null handle");
+    if (!h->finalized) return fail(OG_ESTATE, "og_unet_finalize() has not been called");
+    if (B < 0 || H <= 0 || W <= 0) return fail(OG_EINVAL, "bad B/H/W");
+    const int m = 1 << h->L;
+    if (H % m || W % m)
+        return fail(OG_EINVAL, "H and W must be multiples of 2^n_levels (bilinear fallback of unet.py:84-85 is not implemented)");
+    return OG_OK;
+}
+
+int ensure_stage(og_unet* h, size_t bytes) {
+    if (bytes <= h->stage_bytes) return OG_OK;
+    if (h->stage) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipFree(h->stage));
+        h->stage = nullptr;
+        h->stage_bytes = 0;
+        drop_graphs(h);
+    }
+    HIPCHK(hipMalloc(&h->stage, bytes));
+    h->stage_bytes = bytes;
+    return OG_OK;
+}
+
+inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
+
+}  // namespace
+
+extern "C" {
+
+const char* og_last_error(void) { return g_err.c_str(); }
+const char* og_version(void) { return "openglottal_hip 0.1 (gfx950)"; }
+
+int og_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(OG_ENODEV, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return n;
+}
+
+int og_init(int device) {
+    int n = og_device_count();
+    if (n <= 0) return fail(OG_ENODEV, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(OG_EINVAL, "device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(OG_ENODEV, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    return OG_OK;
+}
+
+void* og_malloc(size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        fail(OG_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+int og_free(void* d) {
+    if (d) HIPCHK(hipFree(d));
+    return OG_OK;
+}
+int og_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return OG_OK;
+}
+int og_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return OG_OK;
+}
+
+og_unet* og_unet_create(const int* features, int n_levels, int in_ch, int out_ch) {
+    if (!features || n_levels < 1 || n_levels > 6) {
+        fail(OG_EINVAL, "features/n_levels invalid (1..6 levels)");
+        return nullptr;
+    }
+    if (in_ch != 1 || out_ch != 1) {
+        fail(OG_EINVAL, "only in_ch=1, out_ch=1 is implemented (the configuration every reference pipeline constructs)");
+        return nullptr;
+    }
+    for (int i = 0; i < n_levels; ++i)
+        if (features[i] < 1 || features[i] > 4096) {
+            fail(OG_EINVAL, "feature width out of range");
+            return nullptr;
+        }
+    og_unet* h = new og_unet();
+    h->features.assign(features, features + n_levels);
+    h->L = n_levels;
+    int ch = 1;
+    for (int i = 0; i < n_levels; ++i) {
+        expect_double_conv(h, "downs." + std::to_string(i), ch, features[i]);
+        ch = features[i];
+    }
+    expect_double_conv(h, "bottleneck", ch, 2 * ch);
+    for (int j = 0; j < n_levels; ++j) {
+        const int f = features[n_levels - 1 - j];
+        expect(h, "ups." + std::to_string(2 * j) + ".weight", {2 * f, f, 2, 2});
+        expect(h, "ups." + std::to_string(2 * j) + ".bias", {f});
+        expect_double_conv(h, "ups." + std::to_string(2 * j + 1), 2 * f, f);
+    }
+    expect(h, "head.weight", {1, features[0], 1, 1});
+    expect(h, "head.bias", {1});
+    return h;
+}
+
+void og_unet_destroy(og_unet* h) {
+    if (!h) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    drop_graphs(h);
+    for (auto* v : {&h->enc_a, &h->enc_b, &h->up_t, &h->dec_a, &h->dec_b})
+        for (auto& l : *v) free_layer(l);
+    free_layer(h->bott_a);
+    free_layer(h->bott_b);
+    for (float* p : {h->d_first_w, h->d_first_scale, h->d_first_shift, h->d_head_w, h->d_zero})
+        if (p) (void)hipFree(p);
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->stage) (void)hipFree(h->stage);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int og_unet_set_tensor(og_unet* h, const char* key, const void* host, const int64_t* shape, int ndim, int dtype) {
+    if (!h || !key || !host) return fail(OG_EINVAL, "null argument");
+    if (h->finalized) return fail(OG_ESTATE, "handle already finalized");
+    const std::string k(key);
+    const std::string nbt = ".num_batches_tracked";
+    if (k.size() > nbt.size() && k.compare(k.size() - nbt.size(), nbt.size(), nbt) == 0) {
+        const std::string bnw = k.substr(0, k.size() - nbt.size()) + ".weight";
+        if (!h->expected.count(bnw)) return fail(OG_EINVAL, "unexpected key " + k);
+        return OG_OK;  // accepted and ignored (eval-mode BN does not use it)
+    }
+    auto it = h->expected.find(k);
+    if (it == h->expected.end()) return fail(OG_EINVAL, "unexpected key " + k);
+    if (dtype != OG_DTYPE_F32) return fail(OG_EINVAL, "tensor " + k + " must be float32");
+    if (ndim < 0 || (ndim > 0 && !shape)) return fail(OG_EINVAL, "bad shape for " + k);
+    std::vector<int64_t> s(shape, shape + ndim);
+    if (s != it->second) {
+        std::string m = "size mismatch for " + k + ": expected [";
+        for (auto v : it->second) m += std::to_string(v) + ",";
+        m += "] got [";
+        for (auto v : s) m += std::to_string(v) + ",";
+        return fail(OG_EINVAL, m + "]");
+    }
+    size_t n = 1;
+    for (auto v : s) n *= (size_t)v;
+    HostTensor t;
+    t.shape = s;
+    t.data.assign((const float*)host, (const float*)host + n);
+    h->host[k] = std::move(t);
+    return OG_OK;
+}
+
+int og_unet_finalize(og_unet* h) {
+    if (!h) return fail(OG_EINVAL, "null handle");
+    if (h->finalized) return OG_OK;
+    std::string missing;
+    for (auto& kv : h->expected)
+        if (!h->host.count(kv.first)) missing += (missing.empty() ? "" : ", ") + kv.first;
+    if (!missing.empty()) return fail(OG_EINVAL, "missing key(s) in state_dict: " + missing);
+
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&h->ev0));
+    HIPCHK(hipEventCreate(&h->ev1));
+    HIPCHK(hipMalloc((void**)&h->d_zero, 4096));
+    HIPCHK(hipMemset(h->d_zero, 0, 4096));
+
+    const int L = h->L;
+    int rc;
+    if ((rc = init_kernel_attrs())) return rc;
+    {  // first layer: [Cout][1][3][3] -> [9][Cp0]
+        const int f0 = h->features[0], Cp0 = cp32(f0);
+        const auto& w = h->host.at("downs.0.net.0.weight").data;
+        std::vector<float> w9((size_t)9 * Cp0, 0.f), sc, sh;
+        for (int co = 0; co < f0; ++co)
+            for (int t = 0; t < 9; ++t) w9[(size_t)t * Cp0 + co] = w[(size_t)co * 9 + t];
+        fold_bn(h, "downs.0.net.1", f0, Cp0, sc, sh);
+        if ((rc = upload(w9, &h->d_first_w))) return rc;
+        if ((rc = upload(sc, &h->d_first_scale))) return rc;
+        if ((rc = upload(sh, &h->d_first_shift))) return rc;
+    }
+    h->enc_a.resize(L);
+    h->enc_b.resize(L);
+    int ch = 1;
+    for (int i = 0; i < L; ++i) {
+        const std::string p = "downs." + std::to_string(i);
+        const int f = h->features[i];
+        if (i > 0 && (rc = build_conv(h, h->enc_a[i], p + ".net.0.weight", p + ".net.1", ch, f, ident_map(ch)))) return rc;
+        if ((rc = build_conv(h, h->enc_b[i], p + ".net.3.weight", p + ".net.4", f, f, ident_map(f)))) return rc;
+        ch = f;
+    }
+    if ((rc = build_conv(h, h->bott_a, "bottleneck.net.0.weight", "bottleneck.net.1", ch, 2 * ch, ident_map(ch)))) return rc;
+    if ((rc = build_conv(h, h->bott_b, "bottleneck.net.3.weight", "bottleneck.net.4", 2 * ch, 2 * ch, ident_map(2 * ch)))) return rc;
+    h->up_t.resize(L);
+    h->dec_a.resize(L);
+    h->dec_b.resize(L);
+    for (int j = 0; j < L; ++j) {
+        const int f = h->features[L - 1 - j];
+        const int Cp = cp32(f);
+        const std::string pt = "ups." + std::to_string(2 * j), pd = "ups." + std::to_string(2 * j + 1);
+        if ((rc = build_convT(h, h->up_t[j], pt, 2 * f, f))) return rc;
+        // cat([skip, up]) (unet.py:86): original ci<f is the skip, ci>=f the up-sampled half
+        std::vector<int> m(2 * Cp, -1);
+        for (int c = 0; c < f; ++c) {
+            m[c] = c;
+            m[Cp + c] = f + c;
+        }
+        if ((rc = build_conv(h, h->dec_a[j], pd + ".net.0.weight", pd + ".net.1", 2 * f, f, m))) return rc;
+        if ((rc = build_conv(h, h->dec_b[j], pd + ".net.3.weight", pd + ".net.4", f, f, ident_map(f)))) return rc;
+    }
+    {
+        const int f0 = h->features[0], Cp0 = cp32(f0);
+        std::vector<float> hw(Cp0, 0.f);
+        const auto& w = h->host.at("head.weight").data;
+        for (int c = 0; c < f0; ++c) hw[c] = w[c];
+        if ((rc = upload(hw, &h->d_head_w))) return rc;
+        h->head_bias = h->host.at("head.bias").data[0];
+    }
+    h->host.clear();
+    h->finalized = true;
+    return OG_OK;
+}
+
+int og_unet_set_chunk(og_unet* h, int n) {
+    if (!h || n < 1 || n > 4096) return fail(OG_EINVAL, "chunk must be in 1..4096");
+    if (n != h->chunk) {
+        h->chunk = n;
+    }
+    return OG_OK;
+}
+
+int og_unet_set_graphs(og_unet* h, int enable) {
+    if (!h) return fail(OG_EINVAL, "null handle");
+    h->use_graphs = enable ? 1 : 0;
+    return OG_OK;
+}
+
+int og_unet_sync(og_unet* h) {
+    if (!h || !h->stream) return fail(OG_ESTATE, "handle not finalized");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return OG_OK;
+}
+
+void* og_unet_stream(og_unet* h) { return h ? (void*)h->stream : nullptr; }
+
+int og_timer_start(og_unet* h) {
+    if (!h || !h->stream) return fail(OG_ESTATE, "handle not finalized");
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    return OG_OK;
+}
+int og_timer_stop(og_unet* h, float* ms) {
+    if (!h || !h->stream || !ms) return fail(OG_ESTATE, "handle not finalized");
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return OG_OK;
+}
+
+int og_unet_segment_u8_dev(og_unet* h, const uint8_t* gray, int B, int H, int W, float thr, const int32_t* boxes,
+                           uint8_t* mask, int32_t* area, float* logits) {
+    int rc = check_shape(h, B, H, W);
+    if (rc) return rc;
+    if (!gray && B > 0) return fail(OG_EINVAL, "gray is null");
+    if (B == 0) return OG_OK;
+    const int cb = h->chunk < B ? h->chunk : B;
+    if ((rc = ensure_arena(h, cb > h->capB ? cb : h->capB, H, W))) return rc;
+    if (area) HIPCHK(hipMemsetAsync(area, 0, (size_t)B * sizeof(int32_t), h->stream));
+    const size_t HW = (size_t)H * W;
+    for (int b0 = 0; b0 < B; b0 += h->chunk) {
+        const int nb = (B - b0 < h->chunk) ? B - b0 : h->chunk;
+        rc = run_chunk(h, KIND_U8, gray + b0 * HW, nb, H, W, thr, boxes ? boxes + 4 * b0 : nullptr,
+                       mask ? mask + b0 * HW : nullptr, area ? area + b0 : nullptr, logits ? logits + b0 * HW : nullptr);
+        if (rc) return rc;
+    }
+    return OG_OK;
+}
+
+int og_unet_segment_u8(og_unet* h, const uint8_t* gray, int B, int H, int W, float thr, const int32_t* boxes,
+                       uint8_t* mask, int32_t* area, float* logits) {
+    int rc = check_shape(h, B, H, W);
+    if (rc) return rc;
+    if (B == 0) return OG_OK;
+    if (!gray) return fail(OG_EINVAL, "gray is null");
+    const size_t HW = (size_t)H * W;
+    const size_t o_gray = 0, o_mask = al256(B * HW), o_area = o_mask + al256(B * HW), o_box = o_area + al256(B * 4),
+                 o_log = o_box + al256(B * 16), tot = o_log + (logits ? al256(B * HW * 4) : 0);
+    if ((rc = ensure_stage(h, tot))) return rc;
+    char* s = (char*)h->stage;
+    HIPCHK(hipMemcpyAsync(s + o_gray, gray, B * HW, hipMemcpyHostToDevice, h->stream));
+    if (boxes) HIPCHK(hipMemcpyAsync(s + o_box, boxes, (size_t)B * 16, hipMemcpyHostToDevice, h->stream));
+    rc = og_unet_segment_u8_dev(h, (const uint8_t*)(s + o_gray), B, H, W, thr, boxes ? (const int32_t*)(s + o_box) : nullptr,
+                                mask ? (uint8_t*)(s + o_mask) : nullptr, area ? (int32_t*)(s + o_area) : nullptr,
+                                logits ? (float*)(s + o_log) : nullptr);
+    if (rc) return rc;
+    if (mask) HIPCHK(hipMemcpyAsync(mask, s + o_mask, B * HW, hipMemcpyDeviceToHost, h->stream));
+    if (area) HIPCHK(hipMemcpyAsync(area, s + o_area, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (logits) HIPCHK(hipMemcpyAsync(logits, s + o_log, B * HW * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return OG_OK;
+}
+
+int og_unet_forward_f32(og_unet* h, const float* x, int B, int H, int W, float* logits) {
+    int rc = check_shape(h, B, H, W);
+    if (rc) return rc;
+    if (B == 0) return OG_OK;
+    if (!x || !logits) return fail(OG_EINVAL, "null buffer");
+    const size_t HW = (size_t)H * W;
+    const size_t o_in = 0, o_out = al256(B * HW * 4), tot = o_out + al256(B * HW * 4);
+    if ((rc = ensure_stage(h, tot))) return rc;
+    char* s = (char*)h->stage;
+    HIPCHK(hipMemcpyAsync(s + o_in, x, B * HW * 4, hipMemcpyHostToDevice, h->stream));
+    const int cb = h->chunk < B ? h->chunk : B;
+    if ((rc = ensure_arena(h, cb > h->capB ? cb : h->capB, H, W))) return rc;
+    for (int b0 = 0; b0 < B; b0 += h->chunk) {
+        const int nb = (B - b0 < h->chunk) ? B - b0 : h->chunk;
+        rc = run_chunk(h, KIND_F32, (const float*)(s + o_in) + b0 * HW, nb, H, W, 0.5f, nullptr, nullptr, nullptr,
+                       (float*)(s + o_out) + b0 * HW);
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(logits, s + o_out, B * HW * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return OG_OK;
+}
+
+int og_mask_area_dev(og_unet* h, const uint8_t* mask, int B, int H, int W, const int32_t* boxes, int32_t* area) {
+    if (!h || !h->finalized) return fail(OG_ESTATE, "handle not finalized");
+    if (!mask || !area || B < 0 || H <= 0 || W <= 0) return fail(OG_EINVAL, "bad argument");
+    if (B == 0) return OG_OK;
+    HIPCHK(hipMemsetAsync(area, 0, (size_t)B * 4, h->stream));
+    const int HW = H * W, bpf = (HW + 4095) / 4096;
+    hipLaunchKernelGGL(k_mask_area, dim3(B * bpf), dim3(256), 0, h->stream, mask, HW, W, boxes, area, bpf);
+    HIPCHK(hipGetLastError());
+    return OG_OK;
+}
+
+int og_bgr2gray_dev(og_unet* h, const uint8_t* bgr, int B, int H, int W, uint8_t* gray) {
+    if (!h || !h->finalized) return fail(OG_ESTATE, "handle not finalized");
+    if (!bgr || !gray || B < 0 || H <= 0 || W <= 0) return fail(OG_EINVAL, "bad argument");
+    const long long n = (long long)B * H * W;
+    if (n == 0) return OG_OK;
+    hipLaunchKernelGGL(k_bgr2gray, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, bgr, gray, n);
+    HIPCHK(hipGetLastError());
+    return OG_OK;
+}
+
+int og_unet_get_activation(og_unet* h, const char* name, int B, float* out, size_t cap, int* dims) {
+    if (!h || !h->finalized || !h->arena) return fail(OG_ESTATE, "no forward has run yet");
+    if (!name || !out || !dims || B < 1 || B > h->lastB) return fail(OG_EINVAL, "bad argument (B must be <= last chunk size)");
+    const std::string n(name);
+    const int L = h->L;
+    const Act* a = nullptr;
+    int off = 0, C = 0;
+    auto level_of_up = [&](int k) { return L - 1 - k / 2; };
+    if (n.rfind("downs.", 0) == 0 && n.size() >= 9) {
+        const int i = atoi(n.c_str() + 6);
+        if (i < 0 || i >= L) return fail(OG_EINVAL, "bad layer " + n);
+        C = h->features[i];
+        if (n.substr(n.size() - 2) == ".a") a = &h->A[i];
+        else if (n.substr(n.size() - 2) == ".b") a = &h->CAT[i];
+    } else if (n.rfind("pool", 0) == 0) {
+        const int i = atoi(n.c_str() + 4);
+        if (i < 0 || i >= L) return fail(OG_EINVAL, "bad layer " + n);
+        a = &h->P[i];
+        C = h->features[i];
+    } else if (n == "bottleneck.a") {
+        a = &h->BA;
+        C = 2 * h->features[L - 1];
+    } else if (n == "bottleneck.b") {
+        a = &h->BB;
+        C = 2 * h->features[L - 1];
+    } else if (n.rfind("ups.", 0) == 0) {
+        const int k = atoi(n.c_str() + 4);
+        if (k < 0 || k >= 2 * L) return fail(OG_EINVAL, "bad layer " + n);
+        const int i = level_of_up(k);
+        C = h->features[i];
+        if (k % 2 == 0) {
+            a = &h->CAT[i];
+            off = cp32(h->features[i]);
+        } else if (n.substr(n.size() - 2) == ".a") a = &h->UA[i];
+        else if (n.substr(n.size() - 2) == ".b") a = &h->UB[i];
+    }
+    if (!a) return fail(OG_EINVAL, "unknown activation name " + n);
+    dims[0] = C;
+    dims[1] = a->H;
+    dims[2] = a->W;
+    const size_t need = (size_t)B * C * a->H * a->W;
+    if (cap < need) return fail(OG_EINVAL, "capacity too small");
+    std::vector<float> tmp((size_t)B * a->frame_stride());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(tmp.data(), a->p, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+    const size_t HW = (size_t)a->H * a->W;
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+            for (size_t p = 0; p < HW; ++p) out[((size_t)b * C + c) * HW + p] = tmp[((size_t)b * HW + p) * a->C + off + c];
+    return OG_OK;
+}
+
+double og_unet_flops_per_frame(og_unet* h, int H, int W) {
+    if (!h) return 0.0;
+    const int L = h->L;
+    double mac = 0;
+    int ch = 1;
+    for (int i = 0; i < L; ++i) {
+        const double px = (double)(H >> i) * (W >> i);
+        mac += px * 9.0 * ch * h->features[i] + px * 9.0 * h->features[i] * h->features[i];
+        ch = h->features[i];
+    }
+    const double pb = (double)(H >> L) * (W >> L);
+    mac += pb * 9.0 * ch * 2 * ch + pb * 9.0 * 2 * ch * 2 * ch;
+    for (int i = L - 1; i >= 0; --i) {
+        const double f = h->features[i];
+        const double pin = (double)(H >> (i + 1)) * (W >> (i + 1));
+        const double px = (double)(H >> i) * (W >> i);
+        mac += pin * 4.0 * (2 * f) * f;             // ConvTranspose2d(2f, f, 2, 2)
+        mac += px * 9.0 * (2 * f) * f + px * 9.0 * f * f;
+    }
+    mac += (double)H * W * h->features[0];           // head 1x1
+    return 2.0 * mac;
+}
+
+}  // extern "C"

@@ -1,0 +1,381 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels for the U-Net forward path.
+//
+// Data layout in HBM: activations are NHWC float32 with the channel count
+// padded to a multiple of 32 ("Cp"); a decoder level's skip and up-sampled
+// tensors live in ONE buffer of 2*Cp channels per pixel (skip in [0,Cp), up in
+// [Cp,2Cp)), so torch.cat([skip, x]) (unet.py:86) never materialises: the
+// encoder conv and the transposed conv write straight into their halves.
+//
+// The 3x3 convolutions (95 % of the FLOPs) and the 2x2/s2
+// transposed convolutions run as im2col-free implicit GEMMs on the exact-f32
+// matrix pipe: v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD, bit-identical to an
+// fmaf chain, MI355X_MICROARCH.md "Matrix cores").  A = pixels (rows) x input
+// channels, B = input channels x output channels, staged through LDS by
+// global_load_lds_dwordx4 (LDS-DMA) with an XOR-swizzled 128-B-row image so the
+// ds_read_b128 fragment reads are (near) bank-conflict-free.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define OG_GLOBAL_AS __attribute__((address_space(1)))
+#define OG_LDS_AS __attribute__((address_space(3)))
+
+// 16-byte LDS-DMA: per-lane global source, wave-uniform LDS base (+ lane*16 by hardware).
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const OG_GLOBAL_AS void*)gsrc, (OG_LDS_AS void*)lds_wave_base, 16, 0, 0);
+}
+
+struct ConvArgs {
+    const float* in;        // NHWC, frame-major
+    long long in_frame_stride;   // floats per frame
+    int in_pix_stride;      // floats per pixel (total channels of the buffer)
+    int in_ch_off;          // first channel this layer reads
+    int n_chunks;           // padded Cin / 32
+    int H, W;               // input spatial size (== output size for the 3x3 conv)
+    int tiles_x, tiles_y;   // 16-wide x TH-high tiles per frame
+    int n_spatial;          // B * tiles_x * tiles_y
+    const float* wpk;       // packed weights, see pack_conv_weights() in og_api.hip
+    const float* scale;     // [aff_mod] folded BN scale (1 for convT)
+    const float* shift;     // [aff_mod] folded BN shift (bias for convT)
+    int aff_mod;            // padded Cout
+    float* out;
+    long long out_frame_stride;
+    int out_pix_stride;
+    int out_ch_off;
+    float* pool;            // optional fused MaxPool2d(2,2) output (unet.py:59,79), or nullptr
+    long long pool_frame_stride;
+    int pool_pix_stride;
+    int pool_ch_off;
+    const float* zero_page; // >= 128 B of zeros: source for the zero padding (padding=1, unet.py:24)
+    int relu;
+};
+
+// MODE 0: 3x3 conv, pad 1, stride 1  (+ per-channel affine, ReLU, optional 2x2 max-pool)
+// MODE 1: 2x2 stride-2 transposed conv as one GEMM with N = 4*Cout (dy,dx,co), scattered store
+// NT    : 32-column output sub-tiles per workgroup (Cout tile = 32*NT); waves are laid out (4/NT) x NT
+// TH    : tile height in pixels (tile is TH x 16)
+template <int NT, int MODE, int TH>
+__global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
+    constexpr int TW = 16;
+    constexpr int PAD = (MODE == 0) ? 1 : 0;
+    constexpr int HW_ = TW + 2 * PAD;
+    constexpr int HH_ = TH + 2 * PAD;
+    constexpr int HALO_PIX = HW_ * HH_;
+    constexpr int HALO_BYTES = HALO_PIX * 128;
+    constexpr int HALO_PIECES = HALO_PIX * 8;
+    constexpr int HALO_IT = (HALO_PIECES + 255) / 256;
+    constexpr int TAPS = (MODE == 0) ? 9 : 1;
+    constexpr int WROWS = 32 * NT;
+    constexpr int WBYTES = WROWS * 128;
+    constexpr int WM = 4 / NT;
+    constexpr int MS = (TH / 2) / WM;  // 32-row M sub-tiles (2 pixel rows x 16) per wave
+    static_assert(MS >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const halo0 = smem;
+    unsigned char* const wbuf0 = smem + 2 * HALO_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % NT;
+    const int wm = wave / NT;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+
+    // ---- tile decode (scalar) ----
+    const int n_tile = blockIdx.x / a.n_spatial;
+    int sp = blockIdx.x - n_tile * a.n_spatial;
+    const int tiles_per_frame = a.tiles_x * a.tiles_y;
+    const int b = sp / tiles_per_frame;
+    sp -= b * tiles_per_frame;
+    const int tyi = sp / a.tiles_x;
+    const int ty0 = tyi * TH;
+    const int tx0 = (sp - tyi * a.tiles_x) * TW;
+
+    const float* in_frame = a.in + (long long)b * a.in_frame_stride + a.in_ch_off;
+
+    // ---- per-thread halo source pointers (fixed across channel chunks) ----
+    const float* hsrc[HALO_IT];
+    int hstep[HALO_IT];
+#pragma unroll
+    for (int it = 0; it < HALO_IT; ++it) {
+        const int q = it * 256 + tid;
+        const int p = q >> 3;
+        const int logical = (q & 7) ^ ((p >> 1) & 7);
+        const int hy = p / HW_;
+        const int hx = p - hy * HW_;
+        const int gy = ty0 + hy - PAD, gx = tx0 + hx - PAD;
+        const bool inb = (q < HALO_PIECES) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        hsrc[it] = inb ? in_frame + ((long long)gy * a.W + gx) * a.in_pix_stride + logical * 4 : a.zero_page + logical * 4;
+        hstep[it] = inb ? 32 : 0;
+    }
+    const bool last_valid = ((HALO_IT - 1) * 256 + tid) < HALO_PIECES;
+
+    auto stage_halo = [&](int buf, int c) {
+        unsigned char* base = halo0 + buf * HALO_BYTES + wave * 1024;
+#pragma unroll
+        for (int it = 0; it < HALO_IT; ++it) {
+            if (it < HALO_IT - 1 || last_valid) glds16(hsrc[it] + c * hstep[it], base + it * 4096);
+        }
+    };
+    const float* wtile = a.wpk + (long long)n_tile * a.n_chunks * TAPS * (WROWS * 32);
+    auto stage_w = [&](int stage, int step) {
+        const float* blk = wtile + (long long)step * (WROWS * 32) + tid * 4;
+        unsigned char* base = wbuf0 + stage * WBYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) glds16(blk + i * 1024, base + i * 4096);
+    };
+
+    // ---- fragment addressing ----
+    // A rows: i -> 2x2-window-major pixel order, so that the 4 accumulator registers
+    // (reg&3) of one lane are exactly one pooling window (see epilogue).
+    const int px0 = 2 * (li >> 2) + (li & 1);
+    const int pyl = (li >> 1) & 1;
+    const int brow = wn * 32 + li;
+    const int boff = brow * 128 + ((lh ^ ((brow >> 1) & 7)) << 4);
+
+    f32x16 acc[MS];
+#pragma unroll
+    for (int m = 0; m < MS; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    const int total_steps = a.n_chunks * TAPS;
+
+    stage_halo(0, 0);
+    stage_w(0, 0);
+    __syncthreads();
+
+    int step = 0;
+    for (int c = 0; c < a.n_chunks; ++c) {
+        const unsigned char* hb = halo0 + (c & 1) * HALO_BYTES;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t, ++step) {
+            if (step + 1 < total_steps) stage_w((step + 1) & 1, step + 1);
+            if (t == 0 && c + 1 < a.n_chunks) stage_halo((c + 1) & 1, c + 1);
+
+            const unsigned char* wb = wbuf0 + (step & 1) * WBYTES;
+            const int dy = (MODE == 0) ? t / 3 : 0;
+            const int dx = (MODE == 0) ? t % 3 : 0;
+            int aoff[MS];
+#pragma unroll
+            for (int m = 0; m < MS; ++m) {
+                const int py = 2 * (wm * MS + m) + pyl + dy;
+                const int p = py * HW_ + px0 + dx;
+                aoff[m] = p * 128 + ((lh ^ ((p >> 1) & 7)) << 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // slot = (2j + lh) ^ swz  ==  ((lh ^ swz) << 4) ^ (j << 5) in bytes
+                const f32x4 bv = *(const f32x4*)(wb + (boff ^ (j << 5)));
+#pragma unroll
+                for (int m = 0; m < MS; ++m) {
+                    const f32x4 av = *(const f32x4*)(hb + (aoff[m] ^ (j << 5)));
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[m], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: affine (+ReLU), store, optional fused 2x2 max-pool ----
+    const int ncol = n_tile * WROWS + wn * 32 + li;  // GEMM column of this lane
+    int co = ncol, qd = 0;
+    if (MODE == 1) {
+        qd = ncol / a.aff_mod;
+        co = ncol - qd * a.aff_mod;
+    }
+    const float sc = a.scale[co];
+    const float sh = a.shift[co];
+    const int OW = (MODE == 1) ? 2 * a.W : a.W;
+    float* out_frame = a.out + (long long)b * a.out_frame_stride + a.out_ch_off + co;
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+        const int ms = wm * MS + m;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int wdw = 2 * g + lh;  // 2x2 window index along x within the sub-tile
+            float vmax = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float v = fmaf(acc[m][4 * g + rr], sc, sh);
+                if (a.relu) v = fmaxf(v, 0.f);
+                const int y = ty0 + 2 * ms + (rr >> 1);
+                const int x = tx0 + 2 * wdw + (rr & 1);
+                if (y < a.H && x < a.W) {
+                    if (MODE == 0) {
+                        out_frame[((long long)y * OW + x) * a.out_pix_stride] = v;
+                    } else {
+                        out_frame[((long long)(2 * y + (qd >> 1)) * OW + (2 * x + (qd & 1))) * a.out_pix_stride] = v;
+                    }
+                }
+                vmax = (rr == 0) ? v : fmaxf(vmax, v);
+            }
+            if (MODE == 0 && a.pool != nullptr) {
+                const int y = ty0 + 2 * ms, x = tx0 + 2 * wdw;
+                if (y < a.H && x < a.W) {
+                    float* pf = a.pool + (long long)b * a.pool_frame_stride + a.pool_ch_off + co;
+                    pf[((long long)(y >> 1) * (a.W >> 1) + (x >> 1)) * a.pool_pix_stride] = vmax;
+                }
+            }
+        }
+    }
+}
+
+// First layer: Conv2d(1, f0, 3, pad 1) + BN + ReLU straight from the u8 frame
+// (fuses `inp.astype(float32) / 255.0`, utils.py:235) or from an f32 NCHW input
+// (UNet.__call__ parity path).  Bandwidth-bound (AI 4.4 F/B): plain
+// VALU, 8 lanes per pixel x 4 channels each -> 1 KiB fully coalesced stores.
+template <typename IN_T>
+__global__ __launch_bounds__(256) void k_conv_first(const IN_T* __restrict__ in, float* __restrict__ out,
+                                                    const float* __restrict__ w9,  // [9][Cp]
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    int H, int W, int Cp, int out_pix_stride, long long out_frame_stride) {
+    __shared__ float tile[18][20];
+    const int tiles_x = (W + 15) >> 4, tiles_y = (H + 15) >> 4;
+    int sp = blockIdx.x;
+    const int b = sp / (tiles_x * tiles_y);
+    sp -= b * tiles_x * tiles_y;
+    const int ty0 = (sp / tiles_x) * 16, tx0 = (sp % tiles_x) * 16;
+    const IN_T* fin = in + (long long)b * H * W;
+    for (int q = threadIdx.x; q < 18 * 18; q += 256) {
+        const int hy = q / 18, hx = q - hy * 18;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            if (sizeof(IN_T) == 1)
+                v = (float)fin[(long long)gy * W + gx] / 255.0f;  // IEEE-correct f32 divide, as numpy's
+            else
+                v = (float)fin[(long long)gy * W + gx];
+        }
+        tile[hy][hx] = v;
+    }
+    __syncthreads();
+    const int cq = threadIdx.x & 7;
+    float* fout = out + (long long)b * out_frame_stride;
+    for (int cg = 0; cg < Cp; cg += 32) {
+        const int c0 = cg + cq * 4;
+        f32x4 wv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[t] = *(const f32x4*)(w9 + t * Cp + c0);
+        const f32x4 sc = *(const f32x4*)(scale + c0);
+        const f32x4 sh = *(const f32x4*)(shift + c0);
+        for (int pp = threadIdx.x >> 3; pp < 256; pp += 32) {
+            const int py = pp >> 4, px = pp & 15;
+            const int y = ty0 + py, x = tx0 + px;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float xv = tile[py + t / 3][px + t % 3];
+                s.x = fmaf(xv, wv[t].x, s.x);
+                s.y = fmaf(xv, wv[t].y, s.y);
+                s.z = fmaf(xv, wv[t].z, s.z);
+                s.w = fmaf(xv, wv[t].w, s.w);
+            }
+            f32x4 o;
+            o.x = fmaxf(fmaf(s.x, sc.x, sh.x), 0.f);
+            o.y = fmaxf(fmaf(s.y, sc.y, sh.y), 0.f);
+            o.z = fmaxf(fmaf(s.z, sc.z, sh.z), 0.f);
+            o.w = fmaxf(fmaf(s.w, sc.w, sh.w), 0.f);
+            if (y < H && x < W) *(f32x4*)(fout + ((long long)y * W + x) * out_pix_stride + c0) = o;
+        }
+    }
+}
+
+// Head: Conv2d(f0, 1, 1) + bias -> logit (unet.py:72,88); sigmoid; > threshold;
+// {0,255} mask (utils.py:237,241); per-frame area = #(mask>0) [inside box]
+// (features.py:238,244-245).  8 lanes per pixel, xor-shuffle reduction.
+__global__ __launch_bounds__(256) void k_head(const float* __restrict__ in, long long in_frame_stride, int in_pix_stride,
+                                              const float* __restrict__ w, float bias, int Cp, int HW, int W,
+                                              float threshold, const int32_t* __restrict__ boxes,
+                                              float* __restrict__ logits, uint8_t* __restrict__ mask,
+                                              int32_t* __restrict__ area, int blocks_per_frame) {
+    const int b = blockIdx.x / blocks_per_frame;
+    const int blk = blockIdx.x - b * blocks_per_frame;
+    const int cq = threadIdx.x & 7;
+    const float* fin = in + (long long)b * in_frame_stride;
+    int bx1 = 0, by1 = 0, bx2 = 1 << 30, by2 = 1 << 30;
+    if (boxes != nullptr) {
+        bx1 = boxes[b * 4 + 0];
+        by1 = boxes[b * 4 + 1];
+        bx2 = boxes[b * 4 + 2];
+        by2 = boxes[b * 4 + 3];
+        if (bx1 < 0) { bx2 = 0; by2 = 0; bx1 = 0; by1 = 0; }  // "no detection" -> area 0 (features.py:241-242)
+        // python slice semantics for mask[y1:y2, x1:x2] with non-negative bounds
+    }
+    int cnt = 0;
+    const int pix_per_block = 1024;
+    for (int pp = threadIdx.x >> 3; pp < pix_per_block; pp += 32) {
+        const int p = blk * pix_per_block + pp;
+        if (p < HW) {
+            float s = 0.f;
+            for (int c = cq * 4; c < Cp; c += 32) {
+                const f32x4 xv = *(const f32x4*)(fin + (long long)p * in_pix_stride + c);
+                const f32x4 wv = *(const f32x4*)(w + c);
+                s = fmaf(xv.x, wv.x, s);
+                s = fmaf(xv.y, wv.y, s);
+                s = fmaf(xv.z, wv.z, s);
+                s = fmaf(xv.w, wv.w, s);
+            }
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            if (cq == 0) {
+                const float lg = s + bias;
+                const float prob = 1.0f / (1.0f + expf(-lg));
+                const bool on = prob > threshold;
+                if (logits) logits[(long long)b * HW + p] = lg;
+                if (mask) mask[(long long)b * HW + p] = on ? 255 : 0;
+                const int y = p / W, x = p - y * W;
+                cnt += (on && x >= bx1 && x < bx2 && y >= by1 && y < by2) ? 1 : 0;
+            }
+        }
+    }
+    if (area != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&area[b], cnt);
+    }
+}
+
+// Box-gated recount over a resident {0,255} mask (features.py:244-245).
+__global__ __launch_bounds__(256) void k_mask_area(const uint8_t* __restrict__ mask, int HW, int W,
+                                                   const int32_t* __restrict__ boxes, int32_t* __restrict__ area,
+                                                   int blocks_per_frame) {
+    const int b = blockIdx.x / blocks_per_frame;
+    const int blk = blockIdx.x - b * blocks_per_frame;
+    int bx1 = 0, by1 = 0, bx2 = 1 << 30, by2 = 1 << 30;
+    if (boxes != nullptr) {
+        bx1 = boxes[b * 4 + 0];
+        by1 = boxes[b * 4 + 1];
+        bx2 = boxes[b * 4 + 2];
+        by2 = boxes[b * 4 + 3];
+        if (bx1 < 0) { bx2 = 0; by2 = 0; bx1 = 0; by1 = 0; }
+    }
+    int cnt = 0;
+    for (int p = blk * 4096 + threadIdx.x; p < min(HW, (blk + 1) * 4096); p += 256) {
+        const int y = p / W, x = p - y * W;
+        cnt += (mask[(long long)b * HW + p] > 0 && x >= bx1 && x < bx2 && y >= by1 && y < by2) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&area[b], cnt);
+}
+
+// cv2.cvtColor(BGR2GRAY) for u8: OpenCV's 15-bit fixed point, coefficients
+// R 9798 / G 19235 / B 3735, (x + 2^14) >> 15.  OpenCV is absent in the build
+// image: this restates its published algorithm; parity unpinned.
+__global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ gray, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int bb = bgr[3 * i], gg = bgr[3 * i + 1], rr = bgr[3 * i + 2];
+        gray[i] = (uint8_t)((bb * 3735 + gg * 19235 + rr * 9798 + (1 << 14)) >> 15);
+    }
+}

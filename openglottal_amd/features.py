@@ -1,0 +1,121 @@
+"""`extract_features_unet` and `_kinematic_features` (`openglottal/features.py`)."""
+
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from ._lib import OpenGlottalHipError
+from .utils import NET_SIZE, bgr_to_gray, normalize_box, unet_segment_frame
+
+
+def _kinematic_features(area_wave) -> dict | None:
+    """Seven scalars of a glottal-area waveform (features.py:38-68).
+
+    ``None`` for a silent (all-zero) waveform; ``f0`` is ``None`` when the
+    spectral peak sits in the first non-DC bin; periodicity is the largest
+    normalised autocorrelation over lags 1..49.
+    """
+    a = np.array(area_wave)
+    if a.max() == 0:
+        return None
+    mu, sd = a.mean(), a.std()
+    centred = a - mu
+    spectrum = np.abs(np.fft.rfft(centred))
+    k = int(np.argmax(spectrum[1:]) + 1)
+    f0 = None if k == 1 else float(np.fft.rfftfreq(len(a))[k])
+    full = np.correlate(centred, centred, mode="full")
+    ac = full[len(full) // 2:]
+    ac /= ac[0] + 1e-8
+    return {
+        "area_mean": mu,
+        "area_std": sd,
+        "area_range": a.max() - a.min(),
+        "open_quotient": float(np.mean(a > mu * 0.1)),
+        "f0": f0,
+        "periodicity": float(ac[1:min(50, len(ac))].max()),
+        "cv": sd / (mu + 1e-8),
+        "_area": a,
+    }
+
+
+def load_frames_bgr(source) -> list[np.ndarray]:
+    """Frames of a video as BGR u8 arrays (utils.py:43-54).
+
+    ``source`` may be an in-memory array/list of frames, a ``.npy``/``.npz`` file
+    (``[N,H,W,3]`` BGR or ``[N,H,W]`` gray), or a video file when OpenCV is
+    importable (AVI/MJPG decode is host I/O and stays on cv2).
+    """
+    if isinstance(source, np.ndarray):
+        return list(source)
+    if isinstance(source, (list, tuple)):
+        return list(source)
+    p = str(source)
+    if p.endswith(".npy"):
+        return list(np.load(p))
+    if p.endswith(".npz"):
+        z = np.load(p)
+        return list(z[z.files[0]])
+    if not os.path.exists(p):
+        return []
+    try:
+        import cv2  # noqa: F401
+    except ImportError as e:
+        raise OpenGlottalHipError(f"decoding {p} needs OpenCV; pass frames as .npy/.npz or an array instead") from e
+    import cv2
+
+    cap = cv2.VideoCapture(p)
+    frames = []
+    while True:
+        ok, frm = cap.read()
+        if not ok:
+            break
+        frames.append(frm)
+    cap.release()
+    return frames
+
+
+def area_waveform(frames, detector, model, device=None, threshold: float = 0.5) -> np.ndarray:
+    """The frame loop of features.py:234-245 as one batched device pass.
+
+    U-Net-only (``detector is None``): area = #(mask>0) per frame.  Gated: the
+    sequential TemporalDetector pass produces one box per frame first (the U-Net
+    does not depend on it), then the fused kernel counts inside the boxes.
+    """
+    if device is not None and getattr(model, "_device", None) is None:
+        model.to(device)
+    frames = list(frames)
+    n = len(frames)
+    if n == 0:
+        return np.zeros(0, np.float64)
+    shapes = {f.shape[:2] for f in frames}
+    boxes = None
+    if detector is not None:
+        detector.reset()
+        boxes = np.empty((n, 4), np.int32)
+        for i, f in enumerate(frames):
+            b = detector.detect(f)
+            boxes[i] = normalize_box(b, f.shape[1], f.shape[0])
+    if shapes == {(NET_SIZE, NET_SIZE)}:
+        gray = np.stack([bgr_to_gray(f) for f in frames])
+        _, area, _ = model.segment(gray, threshold=threshold, boxes=boxes, want_mask=False)
+        return area.astype(np.float64)
+    out = np.zeros(n, np.float64)  # mixed / non-256 frames: per-frame path incl. host resizes
+    for i, f in enumerate(frames):
+        m = unet_segment_frame(bgr_to_gray(f), model, device, threshold)
+        if boxes is None:
+            out[i] = float(np.sum(m > 0))
+        elif boxes[i][0] >= 0:
+            x1, y1, x2, y2 = boxes[i]
+            out[i] = float(np.sum(m[y1:y2, x1:x2] > 0))
+    return out
+
+
+def extract_features_unet(avi_path, detector, model, device=None) -> dict | None:
+    """Drop-in for `openglottal/features.py:202-247` (U-Net-only when ``detector is None``)."""
+    frames = load_frames_bgr(avi_path)
+    if not frames:
+        return None
+    wave = area_waveform(frames, detector, model, device)
+    return _kinematic_features([float(v) for v in wave])

