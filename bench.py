@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Throughput bench of the U-Net-only glottal segmentation path on MI355X.
+
+Counterpart of the reference's scripts/benchmark_video_speed.py:89-109: a "step" is one
+pass of the frame loop (u8 gray frame -> /255 -> U-Net -> sigmoid -> >0.5 -> per-frame
+area) over `--frames` synthetic 256x256 frames per GPU that are already resident in HBM,
+followed by the area-waveform all-gather (RCCL) when N > 1.  Prints ONE JSON line.
+
+  python bench.py                       # 1 GPU
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = f32 vector peak
+DOMINANT = "k_conv_mfma<2,0,8>"
+
+
+def cpu_baseline(sd, budget_s: float = 12.0, max_frames: int = 256):
+    """Reference loop semantics (one frame per call, batch 1) on the host cores, timed on the
+    oracle's torch-CPU restatement (same oneDNN kernels the reference runs)."""
+    import torch
+
+    from oracle import unet_oracle as O
+
+    from openglottal_amd import synth
+
+    sd_t = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+    frames = synth.random_gray_frames(8, seed=3)
+    thr = torch.get_num_threads()
+
+    def one(f):
+        x = torch.from_numpy(f.astype("float32") / 255.0)[None, None]
+        with torch.no_grad():
+            prob = torch.sigmoid(O.forward_torch(sd_t, x)).squeeze().numpy()
+        return float(np.sum(((prob > 0.5).astype(np.uint8) * 255) > 0))
+
+    for i in range(3):
+        one(frames[i])
+    n, t0 = 0, time.perf_counter()
+    while n < max_frames and time.perf_counter() - t0 < budget_s:
+        one(frames[n % 8])
+        n += 1
+    el = time.perf_counter() - t0
+    return {"value": round(n / el, 2), "unit": "frames/s", "cores": int(thr), "kind": "port",
+            "sample": f"{n} frames 256x256, one frame per call (batch 1, fp32), oracle.forward_torch on {thr} host threads, {el:.1f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=512, help="frames per GPU per step (weak scaling)")
+    ap.add_argument("--chunk", type=int, default=16, help="frames per kernel chain (micro-batch of the frame loop)")
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import openglottal_amd as og
+    from openglottal_amd import synth
+    from openglottal_amd.dist import all_gather_areas, env_rank_world
+
+    rank, local_rank, world = env_rank_world()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    feats = (32, 64, 128, 256)
+    sd = synth.make_unet_state_dict(feats, seed=20260227, head_scale=3.4732823371887207, head_bias=-2.890756130218506)
+    model = og.UNet(1, 1, feats)
+    model.load_state_dict(sd)
+    model.to(dev).eval()
+    model.set_chunk(args.chunk)
+    model.set_graphs(not args.no_graphs)
+
+    F = args.frames
+    n_total = F * world
+    lo = rank * F
+    frames = torch.from_numpy(synth.bulk_gray_frames(F, seed=1234 + rank)).to(dev)  # resident in HBM before timing
+    area = torch.zeros(F, dtype=torch.int32, device=dev)
+
+    def step():
+        model.segment_dev(frames, F, 256, 256, area)
+        model.sync()  # kernels run on the handle's stream; the collective on torch's
+        return all_gather_areas(area, n_total) if world > 1 else area
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wave = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wave = step()
+    fence()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    assert wave.numel() == n_total and int(wave.min()) >= 0
+
+    out = None
+    if rank == 0:
+        fps = args.steps * n_total / el
+        out = {
+            "metric": "frames/sec 256x256 U-Net-only", "value": round(fps, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "U-Net-only 256x256 grayscale synthetic video, features (32,64,128,256), "
+                                   "frame loop u8->/255->UNet->sigmoid->>0.5->area, inputs resident in HBM",
+                       "frames_per_gpu_per_step": F, "frames_per_launch": args.chunk, "hip_graphs": not args.no_graphs,
+                       "sharding": f"frames x{world}, all_gather(int32 area) per step" if world > 1 else "none",
+                       "flop_per_frame": model.flops_per_frame(256, 256)},
+            "tflops": round(fps * model.flops_per_frame(256, 256) / 1e12, 2),
+        }
+    if world == 1 and not args.no_roofline:
+        B = min(args.chunk, F)
+        prof = model.profile(frames, B, 256, 256, reps=max(3, min(20, args.steps)))
+        dom = [p for p in prof if p["kernel"] == DOMINANT]
+        fl, ms = sum(p["flops"] for p in dom), sum(p["ms"] for p in dom)
+        tot_ms = sum(p["ms"] for p in prof)
+        ach = fl / (ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "launches_per_chain": len(dom), "avg_launch_ms": round(ms / len(dom), 4),
+                           "share_of_chain_time": round(ms / tot_ms, 3), "frames_per_launch": B,
+                           "chain_ms": round(tot_ms, 3)}
+        out["per_kernel_ms"] = {}
+        for p in prof:
+            out["per_kernel_ms"][p["kernel"]] = round(out["per_kernel_ms"].get(p["kernel"], 0.0) + p["ms"], 4)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sd)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -115,6 +115,13 @@ int og_timer_stop(og_unet* h, float* elapsed_ms);   /* records, synchronises, re
  * Writes C,H,W into dims[3]; returns OG_EINVAL if capacity_floats is too small. */
 int og_unet_get_activation(og_unet* h, const char* name, int B, float* out_nchw, size_t capacity_floats, int* dims);
 
+/* Roofline leg of bench.py: run the chain for B frames `reps` times EAGERLY with a HIP event
+ * pair around every kernel launch (on the handle's stream) and return, per launch in chain
+ * order: layer name and kernel symbol (64-byte slots), mean duration in ms, and the launch's
+ * algorithmic FLOPs (2 x MACs with the true, unpadded channel counts). */
+int og_unet_profile(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, int reps, int max_entries,
+                    char* layers, char* kernels, float* ms, double* flops, int* n_entries);
+
 /* Algorithmic work of one forward at HxW (conv + convT + head MACs x2), for rooflines. */
 double og_unet_flops_per_frame(og_unet* h, int H, int W);
 

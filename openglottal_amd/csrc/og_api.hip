@@ -89,6 +89,14 @@ struct og_unet {
 
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // per-launch profiling (og_unet_profile): when `prof` is set every enqueue_* brackets
+    // its launch with events and records kernel symbol + algorithmic FLOPs
+    struct ProfEntry {
+        std::string layer, kernel;
+        double flops;
+        hipEvent_t e0, e1;
+    };
+    std::vector<ProfEntry>* prof = nullptr;
     int chunk = 16;
     int use_graphs = 1;
     std::map<GraphKey, hipGraphExec_t> graphs;
@@ -283,6 +291,18 @@ int ensure_arena(og_unet* h, int B, int H, int W) {
     return OG_OK;
 }
 
+void prof_begin(og_unet* h, const std::string& layer, const std::string& kernel, double flops) {
+    if (!h->prof) return;
+    og_unet::ProfEntry e{layer, kernel, flops, nullptr, nullptr};
+    (void)hipEventCreate(&e.e0);
+    (void)hipEventCreate(&e.e1);
+    (void)hipEventRecord(e.e0, h->stream);
+    h->prof->push_back(e);
+}
+void prof_end(og_unet* h) {
+    if (h->prof) (void)hipEventRecord(h->prof->back().e1, h->stream);
+}
+
 template <int NT, int MODE, int TH>
 int launch_conv_t(og_unet* h, const ConvArgs& a, int n_ntiles) {
     constexpr int PAD = (MODE == 0) ? 1 : 0;
@@ -337,13 +357,21 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     a.pool_ch_off = 0;
     a.zero_page = h->d_zero;
     a.relu = (L.mode == 0) ? 1 : 0;
+    const double px = (double)B * in.H * in.W;
+    int rc;
     if (L.mode == 0) {
         const int n_ntiles = L.Cout_p / (32 * L.NT);
         if (out.H != in.H || out.W != in.W) return fail(OG_EINVAL, "conv shape mismatch");
-        return (L.NT == 2) ? launch_conv_t<2, 0, TH>(h, a, n_ntiles) : launch_conv_t<1, 0, TH>(h, a, n_ntiles);
+        prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma<2,0,8>" : "k_conv_mfma<1,0,8>", 2.0 * px * 9.0 * L.Cin * L.Cout);
+        rc = (L.NT == 2) ? launch_conv_t<2, 0, TH>(h, a, n_ntiles) : launch_conv_t<1, 0, TH>(h, a, n_ntiles);
+        prof_end(h);
+        return rc;
     }
     if (out.H != 2 * in.H || out.W != 2 * in.W) return fail(OG_EINVAL, "convT shape mismatch");
-    return launch_conv_t<2, 1, TH>(h, a, 4 * L.Cout_p / 64);
+    prof_begin(h, L.name, "k_conv_mfma<2,1,8>", 2.0 * px * 4.0 * L.Cin * L.Cout);
+    rc = launch_conv_t<2, 1, TH>(h, a, 4 * L.Cout_p / 64);
+    prof_end(h);
+    return rc;
 }
 
 enum { KIND_U8 = 0, KIND_F32 = 1 };
@@ -355,12 +383,15 @@ int enqueue_first(og_unet* h, int kind, const void* in, int B, int H, int W) {
     const int Cp0 = cp32(h->features[0]);
     const int tiles = ((W + 15) / 16) * ((H + 15) / 16);
     const Act& o = h->A[0];
+    prof_begin(h, "downs.0.net.0.weight", kind == KIND_U8 ? "k_conv_first<u8>" : "k_conv_first<f32>",
+               2.0 * B * H * W * 9.0 * h->features[0]);
     if (kind == KIND_U8)
         hipLaunchKernelGGL(k_conv_first<uint8_t>, dim3(B * tiles), dim3(256), 0, h->stream, (const uint8_t*)in, o.p,
                            h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride());
     else
         hipLaunchKernelGGL(k_conv_first<float>, dim3(B * tiles), dim3(256), 0, h->stream, (const float*)in, o.p,
                            h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride());
+    prof_end(h);
     HIPCHK(hipGetLastError());
     return OG_OK;
 }
@@ -389,8 +420,10 @@ int enqueue_head(og_unet* h, int B, int H, int W, float thr, const int32_t* boxe
     const Act& u = h->UB[0];
     const int HW = H * W;
     const int bpf = (HW + 1023) / 1024;
+    prof_begin(h, "head", "k_head", 2.0 * B * HW * h->features[0]);
     hipLaunchKernelGGL(k_head, dim3(B * bpf), dim3(256), 0, h->stream, u.p, u.frame_stride(), u.C, h->d_head_w,
                        h->head_bias, cp32(h->features[0]), HW, W, thr, boxes, logits, mask, area, bpf);
+    prof_end(h);
     HIPCHK(hipGetLastError());
     return OG_OK;
 }
@@ -518,6 +551,13 @@ og_unet* og_unet_create(const int* features, int n_levels, int in_ch, int out_ch
     for (int i = 0; i < n_levels; ++i)
         if (features[i] < 1 || features[i] > 4096) {
             fail(OG_EINVAL, "feature width out of range");
+            return nullptr;
+        }
+    for (int i = 1; i < n_levels; ++i)
+        if (features[i] != 2 * features[i - 1]) {
+            // ups[2j] = ConvTranspose2d(f*2, f) consumes the previous level's f*2-channel output
+            // (unet.py:68-70,82): the reference's forward only type-checks when widths double.
+            fail(OG_EINVAL, "features must double per level (reference forward requires features[i+1] == 2*features[i])");
             return nullptr;
         }
     og_unet* h = new og_unet();
@@ -830,6 +870,49 @@ int og_unet_get_activation(og_unet* h, const char* name, int B, float* out, size
     for (int b = 0; b < B; ++b)
         for (int c = 0; c < C; ++c)
             for (size_t p = 0; p < HW; ++p) out[((size_t)b * C + c) * HW + p] = tmp[((size_t)b * HW + p) * a->C + off + c];
+    return OG_OK;
+}
+
+int og_unet_profile(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, int reps, int max_entries, char* layers,
+                    char* kernels, float* ms, double* flops, int* n_entries) {
+    int rc = check_shape(h, B, H, W);
+    if (rc) return rc;
+    if (!gray_dev || B < 1 || reps < 1 || !layers || !kernels || !ms || !flops || !n_entries)
+        return fail(OG_EINVAL, "bad argument");
+    if ((rc = ensure_arena(h, B > h->capB ? B : h->capB, H, W))) return rc;
+    if ((rc = ensure_stage(h, al256((size_t)B * 4)))) return rc;
+    std::vector<double> acc;
+    std::vector<og_unet::ProfEntry> first;
+    for (int r = 0; r < reps; ++r) {
+        std::vector<og_unet::ProfEntry> tr;
+        h->prof = &tr;
+        HIPCHK(hipMemsetAsync(h->stage, 0, (size_t)B * 4, h->stream));
+        rc = enqueue_first(h, KIND_U8, gray_dev, B, H, W);
+        if (!rc) rc = enqueue_body(h, B);
+        if (!rc) rc = enqueue_head(h, B, H, W, 0.5f, nullptr, nullptr, (int32_t*)h->stage, nullptr);
+        h->prof = nullptr;
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (acc.empty()) acc.assign(tr.size(), 0.0);
+        for (size_t i = 0; i < tr.size(); ++i) {
+            float t = 0.f;
+            if (!rc && e == hipSuccess) (void)hipEventElapsedTime(&t, tr[i].e0, tr[i].e1);
+            acc[i] += t;
+            (void)hipEventDestroy(tr[i].e0);
+            (void)hipEventDestroy(tr[i].e1);
+        }
+        if (r == 0) first = tr;
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(OG_EHIP, std::string("profile sync: ") + hipGetErrorString(e));
+    }
+    const int n = (int)first.size();
+    *n_entries = n;
+    if (n > max_entries) return fail(OG_EINVAL, "max_entries too small");
+    for (int i = 0; i < n; ++i) {
+        snprintf(layers + 64 * i, 64, "%s", first[i].layer.c_str());
+        snprintf(kernels + 64 * i, 64, "%s", first[i].kernel.c_str());
+        ms[i] = (float)(acc[i] / reps);
+        flops[i] = first[i].flops;
+    }
     return OG_OK;
 }
 

@@ -158,6 +158,24 @@ class UNet:
         check(lib().og_timer_stop(self._h, C.byref(ms)), "og_timer_stop")
         return float(ms.value)
 
+    def profile(self, gray_dev, B: int, H: int, W: int, reps: int = 5) -> list[dict]:
+        """Per-launch HIP-event timings of one chain (bench.py's roofline leg)."""
+        self._require()
+        n_max = 128
+        layers = C.create_string_buffer(64 * n_max)
+        kernels = C.create_string_buffer(64 * n_max)
+        ms = (C.c_float * n_max)()
+        fl = (C.c_double * n_max)()
+        n = C.c_int(0)
+        check(lib().og_unet_profile(self._h, ptr(gray_dev), B, H, W, reps, n_max, layers, kernels, ms, fl, C.byref(n)),
+              "og_unet_profile")
+        out = []
+        for i in range(n.value):
+            out.append({"layer": layers.raw[64 * i:64 * i + 64].split(b"\0")[0].decode(),
+                        "kernel": kernels.raw[64 * i:64 * i + 64].split(b"\0")[0].decode(),
+                        "ms": float(ms[i]), "flops": float(fl[i])})
+        return out
+
     def flops_per_frame(self, H: int = 256, W: int = 256) -> float:
         self._require()
         return float(lib().og_unet_flops_per_frame(self._h, H, W))

@@ -192,6 +192,8 @@ def test_empty_batch_and_bad_shapes(trained):
     bad["extra.key"] = np.zeros(3, np.float32)
     with pytest.raises(og.OpenGlottalHipError):
         make_model(bad, g["features"])
+    with pytest.raises(og.OpenGlottalHipError):  # widths must double (reference forward would raise too)
+        make_model(synth.make_unet_state_dict((8, 12, 20)), (8, 12, 20))
 
 
 def test_extract_features_unet_matches_reference_kinematics(trained, golden_dir):
@@ -210,8 +212,8 @@ def test_oracle_random_shapes_and_odd_widths():
     """Seeded inputs at sizes the oracle finishes in seconds, incl. channel counts that are
     not multiples of 4/32 and spatial sizes that are not multiples of the 8x16 tile."""
     from oracle import unet_oracle as O
-    cases = [((8, 12, 20), 48, 32, 2), ((5,), 16, 16, 1), ((33, 40), 32, 64, 3), ((32, 64, 128, 256), 64, 48, 1),
-             ((16, 16, 16, 16, 16), 64, 96, 2)]
+    cases = [((6, 12, 24), 48, 32, 2), ((5,), 16, 16, 1), ((33, 66), 32, 64, 3), ((32, 64, 128, 256), 64, 48, 1),
+             ((3, 6, 12, 24, 48), 64, 96, 2)]
     for feats, H, W, B in cases:
         sd = synth.make_unet_state_dict(feats, seed=123 + H, head_scale=2.0, head_bias=-0.3)
         m = make_model(sd, feats)
