@@ -25,6 +25,18 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, den
 DOMINANT = "k_conv_mfma<2,0,8>"
 
 
+def host_cores() -> int:
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(sd, budget_s: float = 12.0, max_frames: int = 256):
     """Reference loop semantics (one frame per call, batch 1) on the host cores, timed on the
     oracle's torch-CPU restatement (same oneDNN kernels the reference runs)."""
@@ -36,7 +48,8 @@ def cpu_baseline(sd, budget_s: float = 12.0, max_frames: int = 256):
 
     sd_t = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
     frames = synth.random_gray_frames(8, seed=3)
-    thr = torch.get_num_threads()
+    thr = host_cores()
+    torch.set_num_threads(thr)
 
     def one(f):
         x = torch.from_numpy(f.astype("float32") / 255.0)[None, None]
@@ -61,7 +74,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=512, help="frames per GPU per step (weak scaling)")
-    ap.add_argument("--chunk", type=int, default=16, help="frames per kernel chain (micro-batch of the frame loop)")
+    ap.add_argument("--chunk", type=int, default=32, help="frames per kernel chain (micro-batch of the frame loop)")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

@@ -100,7 +100,7 @@ int og_bgr2gray_dev(og_unet* h, const uint8_t* bgr_dev, int B, int H, int W, uin
 int og_unet_sync(og_unet* h);
 void* og_unet_stream(og_unet* h);          /* hipStream_t the handle launches on */
 
-/* Micro-batch the frame loop uses per kernel chain (default 16); >=1. */
+/* Micro-batch the frame loop uses per kernel chain (default 32); >=1. */
 int og_unet_set_chunk(og_unet* h, int frames_per_launch);
 /* 1 = replay captured hipGraphs for repeated shapes (default), 0 = eager launches. */
 int og_unet_set_graphs(og_unet* h, int enable);

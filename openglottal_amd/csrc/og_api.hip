@@ -97,7 +97,7 @@ struct og_unet {
         hipEvent_t e0, e1;
     };
     std::vector<ProfEntry>* prof = nullptr;
-    int chunk = 16;
+    int chunk = 32;
     int use_graphs = 1;
     std::map<GraphKey, hipGraphExec_t> graphs;
     int lastB = 0;
