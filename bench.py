@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = f32 vector peak
-DOMINANT = "k_conv_mfma<2,0,8>"
+DOMINANT = "k_conv_mfma_p<2,0,8,1>"
 
 
 def host_cores() -> int:

@@ -105,6 +105,10 @@ int og_unet_set_chunk(og_unet* h, int frames_per_launch);
 /* 1 = replay captured hipGraphs for repeated shapes (default), 0 = eager launches. */
 int og_unet_set_graphs(og_unet* h, int enable);
 
+/* Kernel-selection knobs for A/B measurements (results are bit-identical across them):
+ * "conv_impl" 0|1, "tps_nt1" 1|3|9, "tps_nt2" 1|3, "wg_per_cu" 1|2. */
+int og_unet_set_option(og_unet* h, const char* name, int value);
+
 /* HIP-event timing on the handle's stream (bench.py's roofline leg). */
 int og_timer_start(og_unet* h);
 int og_timer_stop(og_unet* h, float* elapsed_ms);   /* records, synchronises, returns ms since start */
@@ -121,6 +125,15 @@ int og_unet_get_activation(og_unet* h, const char* name, int B, float* out_nchw,
  * algorithmic FLOPs (2 x MACs with the true, unpadded channel counts). */
 int og_unet_profile(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, int reps, int max_entries,
                     char* layers, char* kernels, float* ms, double* flops, int* n_entries);
+
+/* Diagnostic: run one eager chain with {s_memtime, s_memrealtime} stamps at entry/exit of every
+ * persistent conv workgroup and return the median in-kernel shader clock (MHz) per launch, in
+ * chain order (entry 0 = first layer: 0).  Tells "pipe saturated at a DVFS-lowered clock" from
+ * "pipe idle" (MI355X_MICROARCH.md, DVFS give-back item 6).  Not used on the product path. */
+int og_unet_clock_probe(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, int max_entries, double* mhz, int* n_entries);
+
+/* Raw stamps {memtime0, realtime0, memtime1, realtime1} x 1024 workgroups of launch `entry` of the last probe. */
+int og_unet_clock_probe_raw(og_unet* h, int entry, unsigned long long* out4x1024);
 
 /* Algorithmic work of one forward at HxW (conv + convT + head MACs x2), for rooflines. */
 double og_unet_flops_per_frame(og_unet* h, int H, int W);

@@ -48,11 +48,15 @@ PROTOTYPES = {
     "og_unet_stream": (C.c_void_p, [C.c_void_p]),
     "og_unet_set_chunk": (C.c_int, [C.c_void_p, C.c_int]),
     "og_unet_set_graphs": (C.c_int, [C.c_void_p, C.c_int]),
+    "og_unet_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "og_timer_start": (C.c_int, [C.c_void_p]),
     "og_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "og_unet_get_activation": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
     "og_unet_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
                                   C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "og_unet_clock_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                      C.POINTER(C.c_int)]),
+    "og_unet_clock_probe_raw": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "og_unet_flops_per_frame": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
 }
 

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -97,8 +98,14 @@ struct og_unet {
         hipEvent_t e0, e1;
     };
     std::vector<ProfEntry>* prof = nullptr;
+    unsigned long long* d_stamps = nullptr;  // [64 launches][1024 workgroups][4], allocated by og_unet_clock_probe
     int chunk = 32;
     int use_graphs = 1;
+    int conv_impl = 1;   // 0 = k_conv_mfma (one tile per workgroup), 1 = k_conv_mfma_p (persistent, pipelined)
+    int tps_nt1 = 3;     // taps per step for the 32-column kernel
+    int tps_nt2 = 1;     // taps per step for the 64-column kernel
+    int wg_per_cu = 2;   // persistent grid = wg_per_cu * CUs (capped by the item count)
+    int n_cu = 256;
     std::map<GraphKey, hipGraphExec_t> graphs;
     int lastB = 0;
 
@@ -313,6 +320,30 @@ int launch_conv_t(og_unet* h, const ConvArgs& a, int n_ntiles) {
     return OG_OK;
 }
 
+template <int NT, int MODE, int TH, int TPS>
+constexpr int conv_p_lds() {
+    return 2 * (16 + 2 * ((MODE == 0) ? 1 : 0)) * (TH + 2 * ((MODE == 0) ? 1 : 0)) * 128 + 2 * TPS * 32 * NT * 128;
+}
+
+template <int NT, int MODE, int TH, int TPS>
+int launch_conv_p(og_unet* h, const ConvArgs& a, int n_ntiles) {
+    constexpr int lds = conv_p_lds<NT, MODE, TH, TPS>();
+    const int n_items = a.n_spatial * n_ntiles;
+    const int slots = h->n_cu * ((lds > 80 * 1024) ? 1 : h->wg_per_cu);
+    const int rounds = (n_items + slots - 1) / slots;
+    const int grid = (n_items + rounds - 1) / rounds;  // <= slots, balanced: every workgroup gets rounds or rounds-1 items
+    hipLaunchKernelGGL((k_conv_mfma_p<NT, MODE, TH, TPS>), dim3(grid), dim3(256), lds, h->stream, a, n_items);
+    HIPCHK(hipGetLastError());
+    return OG_OK;
+}
+
+template <int NT, int MODE, int TH, int TPS>
+int set_conv_p_attr() {
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_p<NT, MODE, TH, TPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               conv_p_lds<NT, MODE, TH, TPS>()));
+    return OG_OK;
+}
+
 template <int NT, int MODE, int TH>
 int set_conv_attr() {
     constexpr int PAD = (MODE == 0) ? 1 : 0;
@@ -326,6 +357,12 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     if ((rc = set_conv_attr<2, 0, 8>())) return rc;
     if ((rc = set_conv_attr<1, 0, 8>())) return rc;
     if ((rc = set_conv_attr<2, 1, 8>())) return rc;
+    if ((rc = set_conv_p_attr<2, 0, 8, 1>())) return rc;
+    if ((rc = set_conv_p_attr<2, 0, 8, 3>())) return rc;
+    if ((rc = set_conv_p_attr<1, 0, 8, 1>())) return rc;
+    if ((rc = set_conv_p_attr<1, 0, 8, 3>())) return rc;
+    if ((rc = set_conv_p_attr<1, 0, 8, 9>())) return rc;
+    if ((rc = set_conv_p_attr<2, 1, 8, 1>())) return rc;
     return OG_OK;
 }
 
@@ -357,19 +394,51 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     a.pool_ch_off = 0;
     a.zero_page = h->d_zero;
     a.relu = (L.mode == 0) ? 1 : 0;
+    a.stamps = nullptr;
+    if (h->prof && h->d_stamps) {  // diagnostic clock stamps, profile runs only
+        a.stamps = h->d_stamps + 4 * 1024 * h->prof->size();
+    }
     const double px = (double)B * in.H * in.W;
     int rc;
     if (L.mode == 0) {
         const int n_ntiles = L.Cout_p / (32 * L.NT);
         if (out.H != in.H || out.W != in.W) return fail(OG_EINVAL, "conv shape mismatch");
-        prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma<2,0,8>" : "k_conv_mfma<1,0,8>", 2.0 * px * 9.0 * L.Cin * L.Cout);
-        rc = (L.NT == 2) ? launch_conv_t<2, 0, TH>(h, a, n_ntiles) : launch_conv_t<1, 0, TH>(h, a, n_ntiles);
+        const double fl = 2.0 * px * 9.0 * L.Cin * L.Cout;
+        if (h->conv_impl == 0) {
+            prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma<2,0,8>" : "k_conv_mfma<1,0,8>", fl);
+            rc = (L.NT == 2) ? launch_conv_t<2, 0, TH>(h, a, n_ntiles) : launch_conv_t<1, 0, TH>(h, a, n_ntiles);
+        } else if (L.NT == 2) {
+            if (h->tps_nt2 == 3) {
+                prof_begin(h, L.name, "k_conv_mfma_p<2,0,8,3>", fl);
+                rc = launch_conv_p<2, 0, TH, 3>(h, a, n_ntiles);
+            } else {
+                prof_begin(h, L.name, "k_conv_mfma_p<2,0,8,1>", fl);
+                rc = launch_conv_p<2, 0, TH, 1>(h, a, n_ntiles);
+            }
+        } else {
+            if (h->tps_nt1 == 9) {
+                prof_begin(h, L.name, "k_conv_mfma_p<1,0,8,9>", fl);
+                rc = launch_conv_p<1, 0, TH, 9>(h, a, n_ntiles);
+            } else if (h->tps_nt1 == 3) {
+                prof_begin(h, L.name, "k_conv_mfma_p<1,0,8,3>", fl);
+                rc = launch_conv_p<1, 0, TH, 3>(h, a, n_ntiles);
+            } else {
+                prof_begin(h, L.name, "k_conv_mfma_p<1,0,8,1>", fl);
+                rc = launch_conv_p<1, 0, TH, 1>(h, a, n_ntiles);
+            }
+        }
         prof_end(h);
         return rc;
     }
     if (out.H != 2 * in.H || out.W != 2 * in.W) return fail(OG_EINVAL, "convT shape mismatch");
-    prof_begin(h, L.name, "k_conv_mfma<2,1,8>", 2.0 * px * 4.0 * L.Cin * L.Cout);
-    rc = launch_conv_t<2, 1, TH>(h, a, 4 * L.Cout_p / 64);
+    const double flt = 2.0 * px * 4.0 * L.Cin * L.Cout;
+    if (h->conv_impl == 0) {
+        prof_begin(h, L.name, "k_conv_mfma<2,1,8>", flt);
+        rc = launch_conv_t<2, 1, TH>(h, a, 4 * L.Cout_p / 64);
+    } else {
+        prof_begin(h, L.name, "k_conv_mfma_p<2,1,8,1>", flt);
+        rc = launch_conv_p<2, 1, TH, 1>(h, a, 4 * L.Cout_p / 64);
+    }
     prof_end(h);
     return rc;
 }
@@ -592,6 +661,7 @@ void og_unet_destroy(og_unet* h) {
         if (p) (void)hipFree(p);
     if (h->arena) (void)hipFree(h->arena);
     if (h->stage) (void)hipFree(h->stage);
+    if (h->d_stamps) (void)hipFree(h->d_stamps);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -637,6 +707,13 @@ int og_unet_finalize(og_unet* h) {
         if (!h->host.count(kv.first)) missing += (missing.empty() ? "" : ", ") + kv.first;
     if (!missing.empty()) return fail(OG_EINVAL, "missing key(s) in state_dict: " + missing);
 
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDevice(&dev));
+        HIPCHK(hipGetDeviceProperties(&prop, dev));
+        h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
@@ -710,6 +787,23 @@ int og_unet_set_chunk(og_unet* h, int n) {
 int og_unet_set_graphs(og_unet* h, int enable) {
     if (!h) return fail(OG_EINVAL, "null handle");
     h->use_graphs = enable ? 1 : 0;
+    return OG_OK;
+}
+
+int og_unet_set_option(og_unet* h, const char* name, int value) {
+    if (!h || !name) return fail(OG_EINVAL, "null argument");
+    const std::string n(name);
+    int* slot = nullptr;
+    if (n == "conv_impl" && (value == 0 || value == 1)) slot = &h->conv_impl;
+    else if (n == "tps_nt1" && (value == 1 || value == 3 || value == 9)) slot = &h->tps_nt1;
+    else if (n == "tps_nt2" && (value == 1 || value == 3)) slot = &h->tps_nt2;
+    else if (n == "wg_per_cu" && value >= 1 && value <= 2) slot = &h->wg_per_cu;
+    if (!slot) return fail(OG_EINVAL, "unknown option or bad value: " + n);
+    if (*slot != value) {
+        if (h->stream) HIPCHK(hipStreamSynchronize(h->stream));
+        drop_graphs(h);
+        *slot = value;
+    }
     return OG_OK;
 }
 
@@ -913,6 +1007,54 @@ int og_unet_profile(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, in
         ms[i] = (float)(acc[i] / reps);
         flops[i] = first[i].flops;
     }
+    return OG_OK;
+}
+
+int og_unet_clock_probe(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, int max_entries, double* mhz, int* n_entries) {
+    int rc = check_shape(h, B, H, W);
+    if (rc) return rc;
+    if (!gray_dev || !mhz || !n_entries || B < 1) return fail(OG_EINVAL, "bad argument");
+    if ((rc = ensure_arena(h, B > h->capB ? B : h->capB, H, W))) return rc;
+    if ((rc = ensure_stage(h, al256((size_t)B * 4)))) return rc;
+    const size_t nst = (size_t)64 * 1024 * 4;
+    if (!h->d_stamps) HIPCHK(hipMalloc((void**)&h->d_stamps, nst * 8));
+    HIPCHK(hipMemsetAsync(h->d_stamps, 0, nst * 8, h->stream));
+    std::vector<og_unet::ProfEntry> tr;
+    h->prof = &tr;
+    rc = enqueue_first(h, KIND_U8, gray_dev, B, H, W);
+    if (!rc) rc = enqueue_body(h, B);
+    h->prof = nullptr;
+    hipError_t e = hipStreamSynchronize(h->stream);
+    for (auto& t : tr) {
+        (void)hipEventDestroy(t.e0);
+        (void)hipEventDestroy(t.e1);
+    }
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(OG_EHIP, std::string("clock probe sync: ") + hipGetErrorString(e));
+    std::vector<unsigned long long> st(nst);
+    HIPCHK(hipMemcpy(st.data(), h->d_stamps, nst * 8, hipMemcpyDeviceToHost));
+    const int n = (int)tr.size() < 64 ? (int)tr.size() : 64;
+    *n_entries = n;
+    if (n > max_entries) return fail(OG_EINVAL, "max_entries too small");
+    for (int i = 0; i < n; ++i) {
+        std::vector<double> v;
+        for (int w = 0; w < 1024; ++w) {
+            const unsigned long long* q = &st[((size_t)i * 1024 + w) * 4];
+            if (q[3] > q[1] && q[2] > q[0]) v.push_back((double)(q[2] - q[0]) / (double)(q[3] - q[1]) * 100.0);
+        }
+        if (v.empty()) {
+            mhz[i] = 0.0;
+            continue;
+        }
+        std::sort(v.begin(), v.end());
+        mhz[i] = v[v.size() / 2];  // median over workgroups; s_memrealtime ticks at 100 MHz
+    }
+    return OG_OK;
+}
+
+int og_unet_clock_probe_raw(og_unet* h, int entry, unsigned long long* out4x1024) {
+    if (!h || !h->d_stamps || entry < 0 || entry >= 64 || !out4x1024) return fail(OG_EINVAL, "bad argument / no probe run yet");
+    HIPCHK(hipMemcpy(out4x1024, h->d_stamps + (size_t)entry * 4096, 4096 * 8, hipMemcpyDeviceToHost));
     return OG_OK;
 }
 

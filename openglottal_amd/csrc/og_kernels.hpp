@@ -23,9 +23,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define OG_GLOBAL_AS __attribute__((address_space(1)))
 #define OG_LDS_AS __attribute__((address_space(3)))
 
-// 16-byte LDS-DMA: per-lane global source, wave-uniform LDS base (+ lane*16 by hardware).
-__device__ __forceinline__ void glds16(const float* gsrc, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const OG_GLOBAL_AS void*)gsrc, (OG_LDS_AS void*)lds_wave_base, 16, 0, 0);
+// 16-byte LDS-DMA (global_load_lds_dwordx4): per-lane global source, wave-uniform LDS byte
+// address in M0 (+ lane*16 by hardware).  Written as inline asm ON PURPOSE: when hipcc sees the
+// LDS-DMA builtin inside a loop it degrades every later `s_waitcnt lgkmcnt(N)` of that loop to
+// lgkmcnt(0), which exposes the ds_read latency of the register-prefetched MFMA fragments
+// (measured: 86 % -> see DESIGN.md).  The price: hipcc no longer tracks these transfers, so
+// every consumer barrier is preceded by an explicit og_wait_dma() (cdna guide §5.7 item 1).
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_wave_base)
+        : "memory");
+}
+__device__ __forceinline__ void og_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned og_lds_addr(const void* p) {
+    return (unsigned)(size_t)((OG_LDS_AS const unsigned char*)p);
 }
 
 struct ConvArgs {
@@ -51,6 +69,8 @@ struct ConvArgs {
     int pool_ch_off;
     const float* zero_page; // >= 128 B of zeros: source for the zero padding (padding=1, unet.py:24)
     int relu;
+    unsigned long long* stamps;  // diagnostic only (nullptr in production): per workgroup
+                                 // {s_memtime, s_memrealtime} at entry and exit -> in-kernel clock
 };
 
 // MODE 0: 3x3 conv, pad 1, stride 1  (+ per-channel affine, ReLU, optional 2x2 max-pool)
@@ -115,8 +135,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
     }
     const bool last_valid = ((HALO_IT - 1) * 256 + tid) < HALO_PIECES;
 
+    const unsigned lds0 = og_lds_addr(smem);
     auto stage_halo = [&](int buf, int c) {
-        unsigned char* base = halo0 + buf * HALO_BYTES + wave * 1024;
+        const unsigned base = lds0 + buf * HALO_BYTES + wave * 1024;
 #pragma unroll
         for (int it = 0; it < HALO_IT; ++it) {
             if (it < HALO_IT - 1 || last_valid) glds16(hsrc[it] + c * hstep[it], base + it * 4096);
@@ -125,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
     const float* wtile = a.wpk + (long long)n_tile * a.n_chunks * TAPS * (WROWS * 32);
     auto stage_w = [&](int stage, int step) {
         const float* blk = wtile + (long long)step * (WROWS * 32) + tid * 4;
-        unsigned char* base = wbuf0 + stage * WBYTES + wave * 1024;
+        const unsigned base = lds0 + 2 * HALO_BYTES + stage * WBYTES + wave * 1024;
 #pragma unroll
         for (int i = 0; i < NT; ++i) glds16(blk + i * 1024, base + i * 4096);
     };
@@ -148,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
 
     stage_halo(0, 0);
     stage_w(0, 0);
+    og_wait_dma();
     __syncthreads();
 
     int step = 0;
@@ -181,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[m], 0, 0, 0);
                 }
             }
+            og_wait_dma();
             __syncthreads();
         }
     }
@@ -226,6 +249,299 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
                 }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Generation 2 of the implicit-GEMM conv: PERSISTENT workgroups walking a flat sequence of
+// (item = (n_tile, frame, spatial tile), 32-channel chunk, tap-group) steps.
+//   * the next step's weight slices and the next unit's halo (possibly of the NEXT tile) are
+//     always in flight behind the current step's MFMAs -> no per-tile prologue bubble, and the
+//     epilogue stores of tile i overlap the loads of tile i+1;
+//   * A/B fragments are double-buffered in registers, and the one barrier per step sits in
+//     front of the step's LAST k-substep: the first fragments of the next step are read right
+//     behind the barrier and their LDS latency hides under that substep's MFMAs;
+//   * TPS taps per step (weights of TPS taps staged together) trades LDS for barrier count.
+// Same arithmetic, same accumulation order per output element as k_conv_mfma (results are
+// bit-identical between the two).
+template <int NT, int MODE, int TH, int TPS>
+__global__ __launch_bounds__(256, 2) void k_conv_mfma_p(ConvArgs a, int n_items) {
+    constexpr int TW = 16;
+    constexpr int PAD = (MODE == 0) ? 1 : 0;
+    constexpr int HW_ = TW + 2 * PAD;
+    constexpr int HH_ = TH + 2 * PAD;
+    constexpr int HALO_PIX = HW_ * HH_;
+    constexpr int HALO_BYTES = HALO_PIX * 128;
+    constexpr int HALO_PIECES = HALO_PIX * 8;
+    constexpr int HALO_IT = (HALO_PIECES + 255) / 256;
+    constexpr int TAPS = (MODE == 0) ? 9 : 1;
+    static_assert(TAPS % TPS == 0, "TPS must divide the tap count");
+    constexpr int NSTEP_U = TAPS / TPS;  // steps per (item, chunk) unit
+    constexpr int NSUB = TPS * 4;        // k8 sub-steps per step
+    constexpr int WROWS = 32 * NT;
+    constexpr int WBYTES = WROWS * 128;  // one tap slice
+    constexpr int SBYTES = TPS * WBYTES; // one stage
+    constexpr int WM = 4 / NT;
+    constexpr int MS = (TH / 2) / WM;
+    static_assert(MS >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const halo0 = smem;
+    unsigned char* const wbuf0 = smem + 2 * HALO_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % NT;
+    const int wm = wave / NT;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int G = gridDim.x;
+    const int tiles_per_frame = a.tiles_x * a.tiles_y;
+
+    auto decode = [&](int item, int& n_tile, int& b, int& ty0, int& tx0) {
+        n_tile = item / a.n_spatial;
+        int sp = item - n_tile * a.n_spatial;
+        b = sp / tiles_per_frame;
+        sp -= b * tiles_per_frame;
+        const int tyi = sp / a.tiles_x;
+        ty0 = tyi * TH;
+        tx0 = (sp - tyi * a.tiles_x) * TW;
+    };
+
+    // ---- halo prefetch cursor: (h_item, h_c), with per-thread source pointers of h_item ----
+    const float* hsrc[HALO_IT];
+    int hstep[HALO_IT];
+    const bool last_valid = ((HALO_IT - 1) * 256 + tid) < HALO_PIECES;
+    auto set_hsrc = [&](int item) {
+        int n_tile, b, ty0, tx0;
+        decode(item, n_tile, b, ty0, tx0);
+        const float* in_frame = a.in + (long long)b * a.in_frame_stride + a.in_ch_off;
+#pragma unroll
+        for (int it = 0; it < HALO_IT; ++it) {
+            const int q = it * 256 + tid;
+            const int p = q >> 3;
+            const int logical = (q & 7) ^ ((p >> 1) & 7);
+            const int hy = p / HW_;
+            const int hx = p - hy * HW_;
+            const int gy = ty0 + hy - PAD, gx = tx0 + hx - PAD;
+            const bool inb = (q < HALO_PIECES) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            hsrc[it] = inb ? in_frame + ((long long)gy * a.W + gx) * a.in_pix_stride + logical * 4 : a.zero_page + logical * 4;
+            hstep[it] = inb ? 32 : 0;
+        }
+    };
+    const unsigned lds0 = og_lds_addr(smem);
+    auto stage_halo = [&](int buf, int c) {
+        const unsigned base = lds0 + buf * HALO_BYTES + wave * 1024;
+#pragma unroll
+        for (int it = 0; it < HALO_IT; ++it)
+            if (it < HALO_IT - 1 || last_valid) glds16(hsrc[it] + c * hstep[it], base + it * 4096);
+    };
+    // weights of step (n_tile, c, s): TPS consecutive tap slices
+    auto stage_w = [&](int stage, int n_tile, int c, int s) {
+        const float* blk = a.wpk + ((long long)(n_tile * a.n_chunks + c) * TAPS + s * TPS) * (WROWS * 32) + tid * 4;
+        const unsigned base = lds0 + 2 * HALO_BYTES + stage * SBYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NT * TPS; ++i) glds16(blk + i * 1024, base + i * 4096);
+    };
+
+    // ---- fragment addressing ----
+    const int px0 = 2 * (li >> 2) + (li & 1);
+    const int pyl = (li >> 1) & 1;
+    const int brow = wn * 32 + li;
+    const int boff = brow * 128 + ((lh ^ ((brow >> 1) & 7)) << 4);
+    auto a_addr = [&](int m, int tap) -> int {
+        const int dy = (MODE == 0) ? tap / 3 : 0;
+        const int dx = (MODE == 0) ? tap % 3 : 0;
+        const int py = 2 * (wm * MS + m) + pyl + dy;
+        const int p = py * HW_ + px0 + dx;
+        return p * 128 + ((lh ^ ((p >> 1) & 7)) << 4);
+    };
+
+    int item = blockIdx.x;
+    if (item >= n_items) return;
+    if (a.stamps != nullptr && tid == 0) {
+        a.stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+        a.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+
+    // cursors
+    int h_item = item, h_c = 0;           // next halo unit to stage
+    int w_item = item, w_c = 0, w_s = 0;  // next weight step to stage
+    int w_ntile = item / a.n_spatial;
+    set_hsrc(h_item);
+
+    auto adv_h = [&]() {
+        if (++h_c == a.n_chunks) {
+            h_c = 0;
+            h_item += G;
+            if (h_item < n_items) set_hsrc(h_item);
+        }
+    };
+    auto adv_w = [&]() {
+        if (++w_s == NSTEP_U) {
+            w_s = 0;
+            if (++w_c == a.n_chunks) {
+                w_c = 0;
+                w_item += G;
+                w_ntile = w_item / a.n_spatial;
+            }
+        }
+    };
+
+    // prologue: unit 0 halo, step 0 weights
+    stage_halo(0, 0);
+    adv_h();
+    stage_w(0, w_ntile, 0, 0);
+    adv_w();
+    og_wait_dma();
+    __syncthreads();
+
+    f32x4 a_cur[MS], b_cur;
+#pragma unroll
+    for (int m = 0; m < MS; ++m) a_cur[m] = *(const f32x4*)(halo0 + a_addr(m, 0));
+    b_cur = *(const f32x4*)(wbuf0 + boff);
+
+    int u = 0;   // running unit counter  -> halo buffer parity
+    int gs = 0;  // running step counter  -> weight stage parity
+    int cached_ntile = -1;
+    float sc = 0.f, sh = 0.f;
+
+    while (item < n_items) {
+        int n_tile, b, ty0, tx0;
+        decode(item, n_tile, b, ty0, tx0);
+        const bool last_item = (item + G >= n_items);
+
+        f32x16 acc[MS];
+#pragma unroll
+        for (int m = 0; m < MS; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+        for (int c = 0; c < a.n_chunks; ++c) {
+            const bool last_unit = last_item && (c + 1 == a.n_chunks);
+#pragma unroll
+            for (int s = 0; s < NSTEP_U; ++s) {
+                // ---- issue the prefetches that ride behind this step's MFMAs ----
+                if (w_item < n_items) {
+                    stage_w((gs + 1) & 1, w_ntile, w_c, w_s);
+                    adv_w();
+                }
+                if (s == 0 && h_item < n_items) {
+                    stage_halo((u + 1) & 1, h_c);
+                    adv_h();
+                }
+                const unsigned char* hb = halo0 + (u & 1) * HALO_BYTES;
+                const unsigned char* wb = wbuf0 + (gs & 1) * SBYTES;
+                const bool has_next = !(last_unit && s == NSTEP_U - 1);
+#pragma unroll
+                for (int sub = 0; sub < NSUB; ++sub) {
+                    f32x4 a_nxt[MS], b_nxt;
+                    if (sub < NSUB - 1) {
+                        const int tl = (sub + 1) >> 2, j = (sub + 1) & 3;  // tap within step, k8 index
+                        const int tap = s * TPS + tl;
+#pragma unroll
+                        for (int m = 0; m < MS; ++m) a_nxt[m] = *(const f32x4*)(hb + (a_addr(m, tap) ^ (j << 5)));
+                        b_nxt = *(const f32x4*)(wb + tl * WBYTES + (boff ^ (j << 5)));
+                    } else {
+                        // The next step's data was issued >= one step ago: drain the DMA queue, then the
+                        // barrier makes it visible to every wave.  sched_barrier keeps every MFMA of the
+                        // earlier sub-steps ABOVE the barrier, so the fragment reads they were interleaved
+                        // with are long complete and __syncthreads' lgkmcnt(0) is free (hipcc otherwise
+                        // sinks MFMAs below the barrier, which then lands right behind fresh ds_reads).
+                        __builtin_amdgcn_sched_barrier(0);
+                        og_wait_dma();
+                        __syncthreads();
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (has_next) {
+                            const int ns = (s + 1 == NSTEP_U) ? 0 : s + 1;
+                            const unsigned char* hb2 = (s + 1 == NSTEP_U) ? halo0 + ((u + 1) & 1) * HALO_BYTES : hb;
+                            const unsigned char* wb2 = wbuf0 + ((gs + 1) & 1) * SBYTES;
+#pragma unroll
+                            for (int m = 0; m < MS; ++m) a_nxt[m] = *(const f32x4*)(hb2 + a_addr(m, ns * TPS));
+                            b_nxt = *(const f32x4*)(wb2 + boff);
+                        } else {
+#pragma unroll
+                            for (int m = 0; m < MS; ++m) a_nxt[m] = a_cur[m];
+                            b_nxt = b_cur;
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < MS; ++m) {
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m].x, b_cur.x, acc[m], 0, 0, 0);
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m].y, b_cur.y, acc[m], 0, 0, 0);
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m].z, b_cur.z, acc[m], 0, 0, 0);
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m].w, b_cur.w, acc[m], 0, 0, 0);
+                    }
+                    // Schedule: one MFMA, then one fragment ds_read_b128 behind each of the next MS+1
+                    // MFMAs, then the remaining MFMAs.  A ds_read issued inside an MFMA's 64-cycle
+                    // shadow is free; the same reads bunched ahead of the MFMAs cost ~10 cycles each
+                    // (tools/ubench/mfma_f32_issue.hip: 67.6 -> 64.0 cycles per MFMA).
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+                    for (int q = 0; q < MS + 1; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, MS * 4 - (MS + 2), 0);
+#pragma unroll
+                    for (int m = 0; m < MS; ++m) a_cur[m] = a_nxt[m];
+                    b_cur = b_nxt;
+                }
+                ++gs;
+            }
+            ++u;
+        }
+
+        // ---- epilogue: affine (+ReLU), store, optional fused 2x2 max-pool ----
+        const int ncol = n_tile * WROWS + wn * 32 + li;
+        int co = ncol, qd = 0;
+        if (MODE == 1) {
+            qd = ncol / a.aff_mod;
+            co = ncol - qd * a.aff_mod;
+        }
+        if (n_tile != cached_ntile) {  // ordinary loads drain the LDS-DMA queue: keep them rare
+            sc = a.scale[co];
+            sh = a.shift[co];
+            cached_ntile = n_tile;
+        }
+        const int OW = (MODE == 1) ? 2 * a.W : a.W;
+        float* out_frame = a.out + (long long)b * a.out_frame_stride + a.out_ch_off + co;
+#pragma unroll
+        for (int m = 0; m < MS; ++m) {
+            const int ms = wm * MS + m;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int wdw = 2 * g + lh;
+                float vmax = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    float v = fmaf(acc[m][4 * g + rr], sc, sh);
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    const int y = ty0 + 2 * ms + (rr >> 1);
+                    const int x = tx0 + 2 * wdw + (rr & 1);
+                    if (y < a.H && x < a.W) {
+                        if (MODE == 0)
+                            out_frame[((long long)y * OW + x) * a.out_pix_stride] = v;
+                        else
+                            out_frame[((long long)(2 * y + (qd >> 1)) * OW + (2 * x + (qd & 1))) * a.out_pix_stride] = v;
+                    }
+                    vmax = (rr == 0) ? v : fmaxf(vmax, v);
+                }
+                if (MODE == 0 && a.pool != nullptr) {
+                    const int y = ty0 + 2 * ms, x = tx0 + 2 * wdw;
+                    if (y < a.H && x < a.W) {
+                        float* pf = a.pool + (long long)b * a.pool_frame_stride + a.pool_ch_off + co;
+                        pf[((long long)(y >> 1) * (a.W >> 1) + (x >> 1)) * a.pool_pix_stride] = vmax;
+                    }
+                }
+            }
+        }
+        item += G;
+    }
+    if (a.stamps != nullptr && tid == 0) {
+        a.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+        a.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 

@@ -150,6 +150,10 @@ class UNet:
         self._require()
         check(lib().og_unet_set_graphs(self._h, int(bool(enable))), "og_unet_set_graphs")
 
+    def set_option(self, name: str, value: int) -> None:
+        self._require()
+        check(lib().og_unet_set_option(self._h, name.encode(), int(value)), f"og_unet_set_option({name})")
+
     def timer_start(self) -> None:
         check(lib().og_timer_start(self._h), "og_timer_start")
 
@@ -175,6 +179,14 @@ class UNet:
                         "kernel": kernels.raw[64 * i:64 * i + 64].split(b"\0")[0].decode(),
                         "ms": float(ms[i]), "flops": float(fl[i])})
         return out
+
+    def clock_probe(self, gray_dev, B: int, H: int, W: int) -> list[float]:
+        """Median in-kernel shader clock (MHz) per launch of one chain (diagnostic)."""
+        self._require()
+        mhz = (C.c_double * 64)()
+        n = C.c_int(0)
+        check(lib().og_unet_clock_probe(self._h, ptr(gray_dev), B, H, W, 64, mhz, C.byref(n)), "og_unet_clock_probe")
+        return [float(mhz[i]) for i in range(n.value)]
 
     def flops_per_frame(self, H: int = 256, W: int = 256) -> float:
         self._require()

@@ -33,7 +33,7 @@ def _worker(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [10, 11, 1, 502])
+@pytest.mark.parametrize("n", [11, 502])
 def test_all_gather_areas_world2_equals_single_process(n):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -174,6 +174,28 @@ def test_chunking_and_graphs_are_result_invariant(trained):
     assert np.array_equal(base[1].astype(np.int64), g["areas"][:37])
 
 
+def test_kernel_variants_bit_identical(full):
+    """One-tile-per-workgroup kernel vs persistent pipelined kernel, all tap-group sizes: same
+    accumulation order per output element -> bit-identical logits."""
+    g, sd, m, frames, gt = full
+    fr = frames[:5]
+    m.set_option("conv_impl", 0)
+    _, a0, l0 = m.segment(fr, want_mask=False, want_logits=True)
+    try:
+        for impl, t1, t2, wg in [(1, 3, 1, 2), (1, 1, 1, 2), (1, 9, 3, 2), (1, 3, 3, 1)]:
+            m.set_option("conv_impl", impl)
+            m.set_option("tps_nt1", t1)
+            m.set_option("tps_nt2", t2)
+            m.set_option("wg_per_cu", wg)
+            _, a1, l1 = m.segment(fr, want_mask=False, want_logits=True)
+            assert np.array_equal(l0, l1) and np.array_equal(a0, a1), (impl, t1, t2, wg)
+    finally:
+        m.set_option("conv_impl", 1)
+        m.set_option("tps_nt1", 3)
+        m.set_option("tps_nt2", 1)
+        m.set_option("wg_per_cu", 2)
+
+
 def test_empty_batch_and_bad_shapes(trained):
     g, sd, m, frames, gt = trained
     masks, areas, _ = m.segment(np.zeros((0, 256, 256), np.uint8))
