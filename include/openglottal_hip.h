@@ -138,6 +138,30 @@ int og_unet_clock_probe_raw(og_unet* h, int entry, unsigned long long* out4x1024
 /* Algorithmic work of one forward at HxW (conv + convT + head MACs x2), for rooflines. */
 double og_unet_flops_per_frame(og_unet* h, int H, int W);
 
+/* YOLOv8 detector ----------------------------------------------------------
+ * Replaces `self.model(frame_bgr, conf=self.conf, verbose=False)` + `boxes.conf.argmax()` /
+ * `boxes.xyxy[idx]` of TemporalDetector.detect (openglottal/models/detector.py:58-64), i.e. the
+ * ultralytics predictor (BGR->RGB, /255, YOLOv8n, Detect decode) reduced to what the reference
+ * consumes: the highest-confidence box per frame.  ultralytics is a third-party dependency that
+ * the reference neither vendors nor pins: architecture restated from its published sources,
+ * PARITY UNPINNED.  Tensors use ultralytics' own state_dict keys ("model.0.conv.weight", ...),
+ * with BatchNorm (eps 1e-3) or already fused; widths/depths are inferred from the shapes. */
+typedef struct og_yolo og_yolo;
+og_yolo* og_yolo_create(int nc);                      /* nc: number of classes (1 for the glottis detector) */
+void og_yolo_destroy(og_yolo* h);
+int og_yolo_set_tensor(og_yolo* h, const char* key, const void* host, const int64_t* shape, int ndim, int dtype);
+int og_yolo_finalize(og_yolo* h);
+int og_yolo_num_anchors(og_yolo* h, int H, int W);    /* (H/8)(W/8)+(H/16)(W/16)+(H/32)(W/32) */
+/* frames [B,H,W,3] u8 BGR at network resolution (H,W multiples of 32; the caller letterboxes).
+ *   best [B,5] f32: x1,y1,x2,y2,conf of the arg-max-confidence candidate with conf > conf_thres,
+ *                   clipped to the frame; conf = -1 when there is none  (detector.py:61-64)
+ *   pred [B,A,5] f32 or NULL: every decoded candidate (for NMS on the host / parity tests) */
+int og_yolo_detect_u8(og_yolo* h, const uint8_t* bgr, int B, int H, int W, float conf_thres, float* best, float* pred);
+int og_yolo_detect_u8_dev(og_yolo* h, const uint8_t* bgr_dev, int B, int H, int W, float conf_thres, float* best_dev, float* pred_dev);
+int og_yolo_sync(og_yolo* h);
+/* Parity/debug: "model.0" ... "model.21" (module outputs), "box0..2", "cls0..2" (Detect branches), NCHW f32. */
+int og_yolo_get_activation(og_yolo* h, const char* name, int B, float* out_nchw, size_t capacity_floats, int* dims);
+
 #ifdef __cplusplus
 }
 #endif

@@ -325,14 +325,20 @@ constexpr int conv_p_lds() {
     return 2 * (16 + 2 * ((MODE == 0) ? 1 : 0)) * (TH + 2 * ((MODE == 0) ? 1 : 0)) * 128 + 2 * TPS * 32 * NT * 128;
 }
 
+struct LaunchCtx {
+    hipStream_t stream;
+    int n_cu;
+    int wg_per_cu;
+};
+
 template <int NT, int MODE, int TH, int TPS>
-int launch_conv_p(og_unet* h, const ConvArgs& a, int n_ntiles) {
+int launch_conv_p(const LaunchCtx& c, const ConvArgs& a, int n_ntiles) {
     constexpr int lds = conv_p_lds<NT, MODE, TH, TPS>();
     const int n_items = a.n_spatial * n_ntiles;
-    const int slots = h->n_cu * ((lds > 80 * 1024) ? 1 : h->wg_per_cu);
+    const int slots = c.n_cu * ((lds > 80 * 1024) ? 1 : c.wg_per_cu);
     const int rounds = (n_items + slots - 1) / slots;
     const int grid = (n_items + rounds - 1) / rounds;  // <= slots, balanced: every workgroup gets rounds or rounds-1 items
-    hipLaunchKernelGGL((k_conv_mfma_p<NT, MODE, TH, TPS>), dim3(grid), dim3(256), lds, h->stream, a, n_items);
+    hipLaunchKernelGGL((k_conv_mfma_p<NT, MODE, TH, TPS>), dim3(grid), dim3(256), lds, c.stream, a, n_items);
     HIPCHK(hipGetLastError());
     return OG_OK;
 }
@@ -363,6 +369,8 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     if ((rc = set_conv_p_attr<1, 0, 8, 3>())) return rc;
     if ((rc = set_conv_p_attr<1, 0, 8, 9>())) return rc;
     if ((rc = set_conv_p_attr<2, 1, 8, 1>())) return rc;
+    if ((rc = set_conv_p_attr<2, 2, 8, 1>())) return rc;
+    if ((rc = set_conv_p_attr<1, 2, 8, 1>())) return rc;
     return OG_OK;
 }
 
@@ -393,7 +401,12 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     a.pool_pix_stride = pool ? pool->C : 0;
     a.pool_ch_off = 0;
     a.zero_page = h->d_zero;
-    a.relu = (L.mode == 0) ? 1 : 0;
+    a.act = (L.mode == 0) ? 1 : 0;
+    a.res = nullptr;
+    a.res_frame_stride = 0;
+    a.res_pix_stride = 0;
+    a.res_ch_off = 0;
+    const LaunchCtx ctx{h->stream, h->n_cu, h->wg_per_cu};
     a.stamps = nullptr;
     if (h->prof && h->d_stamps) {  // diagnostic clock stamps, profile runs only
         a.stamps = h->d_stamps + 4 * 1024 * h->prof->size();
@@ -410,21 +423,21 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         } else if (L.NT == 2) {
             if (h->tps_nt2 == 3) {
                 prof_begin(h, L.name, "k_conv_mfma_p<2,0,8,3>", fl);
-                rc = launch_conv_p<2, 0, TH, 3>(h, a, n_ntiles);
+                rc = launch_conv_p<2, 0, TH, 3>(ctx, a, n_ntiles);
             } else {
                 prof_begin(h, L.name, "k_conv_mfma_p<2,0,8,1>", fl);
-                rc = launch_conv_p<2, 0, TH, 1>(h, a, n_ntiles);
+                rc = launch_conv_p<2, 0, TH, 1>(ctx, a, n_ntiles);
             }
         } else {
             if (h->tps_nt1 == 9) {
                 prof_begin(h, L.name, "k_conv_mfma_p<1,0,8,9>", fl);
-                rc = launch_conv_p<1, 0, TH, 9>(h, a, n_ntiles);
+                rc = launch_conv_p<1, 0, TH, 9>(ctx, a, n_ntiles);
             } else if (h->tps_nt1 == 3) {
                 prof_begin(h, L.name, "k_conv_mfma_p<1,0,8,3>", fl);
-                rc = launch_conv_p<1, 0, TH, 3>(h, a, n_ntiles);
+                rc = launch_conv_p<1, 0, TH, 3>(ctx, a, n_ntiles);
             } else {
                 prof_begin(h, L.name, "k_conv_mfma_p<1,0,8,1>", fl);
-                rc = launch_conv_p<1, 0, TH, 1>(h, a, n_ntiles);
+                rc = launch_conv_p<1, 0, TH, 1>(ctx, a, n_ntiles);
             }
         }
         prof_end(h);
@@ -437,7 +450,7 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         rc = launch_conv_t<2, 1, TH>(h, a, 4 * L.Cout_p / 64);
     } else {
         prof_begin(h, L.name, "k_conv_mfma_p<2,1,8,1>", flt);
-        rc = launch_conv_p<2, 1, TH, 1>(h, a, 4 * L.Cout_p / 64);
+        rc = launch_conv_p<2, 1, TH, 1>(ctx, a, 4 * L.Cout_p / 64);
     }
     prof_end(h);
     return rc;
@@ -561,6 +574,8 @@ int ensure_stage(og_unet* h, size_t bytes) {
 inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 
 }  // namespace
+
+#include "og_yolo.inc"
 
 extern "C" {
 

@@ -41,6 +41,11 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_wave_base
         : "v"(gsrc), "s"(lds_wave_base)
         : "memory");
 }
+__device__ __forceinline__ float og_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return v / (1.0f + expf(-v));  // SiLU = x * sigmoid(x)
+    return v;
+}
 __device__ __forceinline__ void og_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned og_lds_addr(const void* p) {
     return (unsigned)(size_t)((OG_LDS_AS const unsigned char*)p);
@@ -68,7 +73,11 @@ struct ConvArgs {
     int pool_pix_stride;
     int pool_ch_off;
     const float* zero_page; // >= 128 B of zeros: source for the zero padding (padding=1, unet.py:24)
-    int relu;
+    int act;                // 0 none, 1 ReLU (U-Net), 2 SiLU (YOLOv8 Conv block)
+    const float* res;       // optional residual added AFTER the activation (YOLOv8 Bottleneck shortcut), or nullptr
+    long long res_frame_stride;
+    int res_pix_stride;
+    int res_ch_off;
     unsigned long long* stamps;  // diagnostic only (nullptr in production): per workgroup
                                  // {s_memtime, s_memrealtime} at entry and exit -> in-kernel clock
 };
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 float v = fmaf(acc[m][4 * g + rr], sc, sh);
-                if (a.relu) v = fmaxf(v, 0.f);
+                v = og_act(v, a.act);
                 const int y = ty0 + 2 * ms + (rr >> 1);
                 const int x = tx0 + 2 * wdw + (rr & 1);
                 if (y < a.H && x < a.W) {
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
 //     behind the barrier and their LDS latency hides under that substep's MFMAs;
 //   * TPS taps per step (weights of TPS taps staged together) trades LDS for barrier count.
 // Same arithmetic, same accumulation order per output element as k_conv_mfma (results are
-// bit-identical between the two).
+// bit-identical between the two).  MODE 2 (this kernel only): 1x1 conv, no halo, plain epilogue.
 template <int NT, int MODE, int TH, int TPS>
 __global__ __launch_bounds__(256, 2) void k_conv_mfma_p(ConvArgs a, int n_items) {
     constexpr int TW = 16;
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_p(ConvArgs a, int n_items)
     constexpr int HALO_BYTES = HALO_PIX * 128;
     constexpr int HALO_PIECES = HALO_PIX * 8;
     constexpr int HALO_IT = (HALO_PIECES + 255) / 256;
-    constexpr int TAPS = (MODE == 0) ? 9 : 1;
+    constexpr int TAPS = (MODE == 0) ? 9 : 1;  // MODE 1 (convT) and MODE 2 (1x1): one tap
     static_assert(TAPS % TPS == 0, "TPS must divide the tap count");
     constexpr int NSTEP_U = TAPS / TPS;  // steps per (item, chunk) unit
     constexpr int NSUB = TPS * 4;        // k8 sub-steps per step
@@ -517,14 +526,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_p(ConvArgs a, int n_items)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     float v = fmaf(acc[m][4 * g + rr], sc, sh);
-                    if (a.relu) v = fmaxf(v, 0.f);
+                    v = og_act(v, a.act);
                     const int y = ty0 + 2 * ms + (rr >> 1);
                     const int x = tx0 + 2 * wdw + (rr & 1);
                     if (y < a.H && x < a.W) {
-                        if (MODE == 0)
+                        if (MODE != 1) {
+                            if (a.res != nullptr)
+                                v += a.res[(long long)b * a.res_frame_stride + ((long long)y * OW + x) * a.res_pix_stride + a.res_ch_off + co];
                             out_frame[((long long)y * OW + x) * a.out_pix_stride] = v;
-                        else
+                        } else {
                             out_frame[((long long)(2 * y + (qd >> 1)) * OW + (2 * x + (qd & 1))) * a.out_pix_stride] = v;
+                        }
                     }
                     vmax = (rr == 0) ? v : fmaxf(vmax, v);
                 }
@@ -693,5 +705,232 @@ __global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t* __restrict__ bg
     if (i < n) {
         const int bb = bgr[3 * i], gg = bgr[3 * i + 1], rr = bgr[3 * i + 2];
         gray[i] = (uint8_t)((bb * 3735 + gg * 19235 + rr * 9798 + (1 << 14)) >> 15);
+    }
+}
+
+// =======================================================================================
+// YOLOv8n detector kernels (rows D2 / Y1-Y6 of SURVEY §8a).  The network itself is
+// third-party (ultralytics, not vendored by the reference): architecture restated from its
+// published yolov8.yaml / modules — parity unpinned.  3x3 s1 and 1x1 convolutions reuse
+// k_conv_mfma_p (MODE 0 / MODE 2, SiLU epilogue, optional Bottleneck residual).
+// =======================================================================================
+
+// Generic direct convolution (any k, stride, pad; NHWC f32, or the u8 BGR frame with the
+// predictor's BGR->RGB swap and /255 fused).  Used for the seven stride-2 convs (~15 % of the
+// detector's MACs); 8 lanes per output pixel x 4 output channels each.
+// Weights: [k*k][Cin][Cout_p] (Cout contiguous).
+template <bool IN_U8>
+__global__ __launch_bounds__(256) void k_conv_direct(const void* __restrict__ in_, long long in_frame_stride, int in_pix_stride,
+                                                     int in_ch_off, int Hin, int Win, int Cin, const float* __restrict__ w,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     int Cout_p, float* __restrict__ out, long long out_frame_stride,
+                                                     int out_pix_stride, int out_ch_off, int Hout, int Wout, int ks, int stride,
+                                                     int pad, int act, int total_pix) {
+    const int cq = threadIdx.x & 7;
+    const int p = blockIdx.x * 32 + (threadIdx.x >> 3);
+    if (p >= total_pix) return;
+    const int hw = Hout * Wout;
+    const int b = p / hw;
+    const int rem = p - b * hw;
+    const int oy = rem / Wout, ox = rem - oy * Wout;
+    for (int cg = 0; cg < Cout_p; cg += 32) {
+        const int c0 = cg + cq * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < ks; ++ky) {
+            const int iy = oy * stride - pad + ky;
+            if (iy < 0 || iy >= Hin) continue;
+            for (int kx = 0; kx < ks; ++kx) {
+                const int ix = ox * stride - pad + kx;
+                if (ix < 0 || ix >= Win) continue;
+                const float* wp = w + (long long)((ky * ks + kx) * Cin) * Cout_p + c0;
+                if (IN_U8) {
+                    const uint8_t* px = (const uint8_t*)in_ + ((long long)b * Hin * Win + (long long)iy * Win + ix) * 3;
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) {
+                        const float xv = (float)px[2 - ci] / 255.0f;  // network channel ci = RGB[ci] = BGR[2-ci]
+                        const f32x4 wv = *(const f32x4*)(wp + ci * Cout_p);
+                        acc.x = fmaf(xv, wv.x, acc.x);
+                        acc.y = fmaf(xv, wv.y, acc.y);
+                        acc.z = fmaf(xv, wv.z, acc.z);
+                        acc.w = fmaf(xv, wv.w, acc.w);
+                    }
+                } else {
+                    const float* xp = (const float*)in_ + (long long)b * in_frame_stride + ((long long)iy * Win + ix) * in_pix_stride + in_ch_off;
+                    for (int ci = 0; ci < Cin; ci += 4) {
+                        const f32x4 xv = *(const f32x4*)(xp + ci);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (ci + e < Cin) {
+                                const f32x4 wv = *(const f32x4*)(wp + (long long)(ci + e) * Cout_p);
+                                acc.x = fmaf(xv[e], wv.x, acc.x);
+                                acc.y = fmaf(xv[e], wv.y, acc.y);
+                                acc.z = fmaf(xv[e], wv.z, acc.z);
+                                acc.w = fmaf(xv[e], wv.w, acc.w);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        const f32x4 sc = *(const f32x4*)(scale + c0);
+        const f32x4 sh = *(const f32x4*)(shift + c0);
+        f32x4 o;
+        o.x = og_act(fmaf(acc.x, sc.x, sh.x), act);
+        o.y = og_act(fmaf(acc.y, sc.y, sh.y), act);
+        o.z = og_act(fmaf(acc.z, sc.z, sh.z), act);
+        o.w = og_act(fmaf(acc.w, sc.w, sh.w), act);
+        *(f32x4*)(out + (long long)b * out_frame_stride + ((long long)oy * Wout + ox) * out_pix_stride + out_ch_off + c0) = o;
+    }
+}
+
+// SPPF's MaxPool2d(5, stride 1, pad 2) (-inf padding), channel segment -> channel segment of one buffer.
+__global__ __launch_bounds__(256) void k_maxpool5(const float* __restrict__ buf_in, float* __restrict__ buf_out, long long frame_stride,
+                                                  int pix_stride, int in_off, int out_off, int C4 /*channels/4*/, int H, int W, long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int c = (int)(t % C4) * 4;
+    long long p = t / C4;
+    const int x = (int)(p % W);
+    p /= W;
+    const int y = (int)(p % H);
+    const long long b = p / H;
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int dy = -2; dy <= 2; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            const f32x4 v = *(const f32x4*)(buf_in + b * frame_stride + ((long long)yy * W + xx) * pix_stride + in_off + c);
+            m.x = fmaxf(m.x, v.x);
+            m.y = fmaxf(m.y, v.y);
+            m.z = fmaxf(m.z, v.z);
+            m.w = fmaxf(m.w, v.w);
+        }
+    }
+    *(f32x4*)(buf_out + b * frame_stride + ((long long)y * W + x) * pix_stride + out_off + c) = m;
+}
+
+// nn.Upsample(scale_factor=2, mode="nearest"): out[y][x] = in[y/2][x/2], into a channel segment.
+__global__ __launch_bounds__(256) void k_upsample2(const float* __restrict__ in, long long in_frame_stride, int in_pix_stride, int in_off,
+                                                   float* __restrict__ out, long long out_frame_stride, int out_pix_stride,
+                                                   int out_off, int C4, int Hout, int Wout, long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int c = (int)(t % C4) * 4;
+    long long p = t / C4;
+    const int x = (int)(p % Wout);
+    p /= Wout;
+    const int y = (int)(p % Hout);
+    const long long b = p / Hout;
+    const f32x4 v = *(const f32x4*)(in + b * in_frame_stride + ((long long)(y >> 1) * (Wout >> 1) + (x >> 1)) * in_pix_stride + in_off + c);
+    *(f32x4*)(out + b * out_frame_stride + ((long long)y * Wout + x) * out_pix_stride + out_off + c) = v;
+}
+
+// Detect head decode: DFL (softmax expectation over 16 bins per side), dist2bbox around the
+// anchor centre (x+0.5, y+0.5), x stride, sigmoid class score; then the per-frame arg-max
+// confidence box >= conf_thres.  NMS never changes which box has the highest confidence, and
+// TemporalDetector consumes exactly `boxes.xyxy[boxes.conf.argmax()]` (detector.py:62-64), so the
+// top-1 needs no NMS.  One workgroup per frame.  pred [B][A][5] = x1,y1,x2,y2,conf (optional);
+// best [B][5] (conf = -1 when nothing passes).
+struct YoloLevel {
+    const float* box;   // [B,h,w,*] 64 DFL logits at ch 0
+    const float* cls;   // [B,h,w,*] class logit at ch 0
+    long long box_frame_stride, cls_frame_stride;
+    int box_pix_stride, cls_pix_stride;
+    int h, w;
+    float stride;
+};
+struct YoloDecodeArgs {
+    YoloLevel lv[3];
+    int n_anchors;
+    float conf_thres;
+    float img_w, img_h;  // clip range (scale_boxes -> clip_boxes for the identity letterbox)
+    float* pred;
+    float* best;
+};
+__global__ __launch_bounds__(256) void k_yolo_decode(YoloDecodeArgs a) {
+    __shared__ float s_conf[256];
+    __shared__ int s_idx[256];
+    const int b = blockIdx.x;
+    float best_c = -1.f;
+    int best_i = 0x7fffffff;
+    float bx[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < a.n_anchors; i += 256) {
+        int l = 0, j = i;
+        if (j >= a.lv[0].h * a.lv[0].w) {
+            j -= a.lv[0].h * a.lv[0].w;
+            l = 1;
+            if (j >= a.lv[1].h * a.lv[1].w) {
+                j -= a.lv[1].h * a.lv[1].w;
+                l = 2;
+            }
+        }
+        const YoloLevel& L = a.lv[l];
+        const int y = j / L.w, x = j - y * L.w;
+        const float* bp = L.box + (long long)b * L.box_frame_stride + (long long)j * L.box_pix_stride;
+        float d[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float v[16], mx = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                v[q] = bp[s * 16 + q];
+                mx = fmaxf(mx, v[q]);
+            }
+            float se = 0.f, sw = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float e = expf(v[q] - mx);
+                se += e;
+                sw += e * (float)q;
+            }
+            d[s] = sw / se;
+        }
+        const float ax = (float)x + 0.5f, ay = (float)y + 0.5f;
+        const float x1a = ax - d[0], y1a = ay - d[1], x2a = ax + d[2], y2a = ay + d[3];
+        const float cx = (x1a + x2a) * 0.5f * L.stride, cy = (y1a + y2a) * 0.5f * L.stride;
+        const float ww = (x2a - x1a) * L.stride, hh = (y2a - y1a) * L.stride;
+        const float lg = L.cls[(long long)b * L.cls_frame_stride + (long long)j * L.cls_pix_stride];
+        const float conf = 1.0f / (1.0f + expf(-lg));
+        float r[4] = {cx - ww * 0.5f, cy - hh * 0.5f, cx + ww * 0.5f, cy + hh * 0.5f};
+        r[0] = fminf(fmaxf(r[0], 0.f), a.img_w);
+        r[2] = fminf(fmaxf(r[2], 0.f), a.img_w);
+        r[1] = fminf(fmaxf(r[1], 0.f), a.img_h);
+        r[3] = fminf(fmaxf(r[3], 0.f), a.img_h);
+        if (a.pred) {
+            float* pp = a.pred + ((long long)b * a.n_anchors + i) * 5;
+            pp[0] = r[0]; pp[1] = r[1]; pp[2] = r[2]; pp[3] = r[3]; pp[4] = conf;
+        }
+        if (conf > a.conf_thres && (conf > best_c)) {  // strict >: the first (lowest index) maximum wins, as argmax
+            best_c = conf;
+            best_i = i;
+            bx[0] = r[0]; bx[1] = r[1]; bx[2] = r[2]; bx[3] = r[3];
+        }
+    }
+    s_conf[threadIdx.x] = best_c;
+    s_idx[threadIdx.x] = best_i;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float c2 = s_conf[threadIdx.x + o];
+            const int i2 = s_idx[threadIdx.x + o];
+            if (c2 > s_conf[threadIdx.x] || (c2 == s_conf[threadIdx.x] && i2 < s_idx[threadIdx.x])) {
+                s_conf[threadIdx.x] = c2;
+                s_idx[threadIdx.x] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    const int win = s_idx[0];
+    if (s_conf[0] < 0.f) {
+        if (threadIdx.x == 0) {
+            float* o = a.best + (long long)b * 5;
+            o[0] = o[1] = o[2] = o[3] = 0.f;
+            o[4] = -1.f;
+        }
+    } else if (best_i == win && best_c == s_conf[0]) {
+        float* o = a.best + (long long)b * 5;
+        o[0] = bx[0]; o[1] = bx[1]; o[2] = bx[2]; o[3] = bx[3]; o[4] = best_c;
     }
 }

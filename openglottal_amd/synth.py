@@ -134,3 +134,80 @@ def glottis_frames(
             frames.append(np.clip(np.rint(img), 0, 255).astype(np.uint8))
             gts.append(inside.astype(np.uint8) * 255)
     return np.stack(frames), np.stack(gts)
+
+
+# ── YOLOv8 detector weights (ultralytics state_dict keys) ────────────────────
+
+
+def make_yolov8_state_dict(seed: int = 7, nc: int = 1, width: float = 0.25, depth: float = 0.33,
+                           max_channels: int = 1024, cls_bias: float = 0.0, fused: bool = False) -> dict[str, np.ndarray]:
+    """Random-init YOLOv8 (default: scale ``n``) under ultralytics' key names.
+
+    The reference's detector weights (`weights/openglottal_yolo.pt`) are missing from the snapshot
+    and are an ultralytics pickle anyway; this produces a flat ``{key: ndarray}`` of the same
+    architecture (yolov8.yaml: widths ×``width`` capped at ``max_channels``, C2f repeats ×``depth``)
+    so the detector path can be exercised and timed.  ``fused=True`` emits conv.weight/conv.bias
+    (what ``model.fuse()`` leaves) instead of BatchNorm tensors.
+    """
+    rs = np.random.RandomState(seed)
+    sd: dict[str, np.ndarray] = {}
+
+    def ch(c):
+        return int(np.ceil(min(c, max_channels) * width / 8) * 8)
+
+    def rep(n):
+        return max(round(n * depth), 1)
+
+    def conv(p, c1, c2, k):
+        bound = np.sqrt(6.0 / (c1 * k * k))
+        sd[p + ".conv.weight"] = rs.uniform(-bound, bound, (c2, c1, k, k)).astype(np.float32)
+        if fused:
+            sd[p + ".conv.bias"] = rs.uniform(-0.1, 0.1, c2).astype(np.float32)
+            return
+        sd[p + ".bn.weight"] = rs.uniform(0.8, 1.2, c2).astype(np.float32)
+        sd[p + ".bn.bias"] = rs.uniform(-0.1, 0.1, c2).astype(np.float32)
+        sd[p + ".bn.running_mean"] = rs.uniform(-0.1, 0.1, c2).astype(np.float32)
+        sd[p + ".bn.running_var"] = rs.uniform(0.5, 1.5, c2).astype(np.float32)
+        sd[p + ".bn.num_batches_tracked"] = np.array(10, dtype=np.int64)
+
+    def c2f(p, c1, c2, n):
+        c = c2 // 2
+        conv(p + ".cv1", c1, 2 * c, 1)
+        conv(p + ".cv2", (2 + n) * c, c2, 1)
+        for j in range(n):
+            conv(f"{p}.m.{j}.cv1", c, c, 3)
+            conv(f"{p}.m.{j}.cv2", c, c, 3)
+
+    c64, c128, c256, c512, c1024 = ch(64), ch(128), ch(256), ch(512), ch(1024)
+    conv("model.0", 3, c64, 3)
+    conv("model.1", c64, c128, 3)
+    c2f("model.2", c128, c128, rep(3))
+    conv("model.3", c128, c256, 3)
+    c2f("model.4", c256, c256, rep(6))
+    conv("model.5", c256, c512, 3)
+    c2f("model.6", c512, c512, rep(6))
+    conv("model.7", c512, c1024, 3)
+    c2f("model.8", c1024, c1024, rep(3))
+    conv("model.9.cv1", c1024, c1024 // 2, 1)
+    conv("model.9.cv2", c1024 // 2 * 4, c1024, 1)
+    c2f("model.12", c1024 + c512, c512, rep(3))
+    c2f("model.15", c512 + c256, c256, rep(3))
+    conv("model.16", c256, c256, 3)
+    c2f("model.18", c256 + c512, c512, rep(3))
+    conv("model.19", c512, c512, 3)
+    c2f("model.21", c512 + c1024, c1024, rep(3))
+    feats = (c256, c512, c1024)
+    reg_max = 16
+    cb = max(16, feats[0] // 4, reg_max * 4)
+    cc = max(feats[0], min(nc, 100))
+    for l, f in enumerate(feats):
+        conv(f"model.22.cv2.{l}.0", f, cb, 3)
+        conv(f"model.22.cv2.{l}.1", cb, cb, 3)
+        sd[f"model.22.cv2.{l}.2.weight"] = rs.uniform(-0.1, 0.1, (4 * reg_max, cb, 1, 1)).astype(np.float32)
+        sd[f"model.22.cv2.{l}.2.bias"] = rs.uniform(0.5, 1.5, 4 * reg_max).astype(np.float32)
+        conv(f"model.22.cv3.{l}.0", f, cc, 3)
+        conv(f"model.22.cv3.{l}.1", cc, cc, 3)
+        sd[f"model.22.cv3.{l}.2.weight"] = rs.uniform(-0.3, 0.3, (nc, cc, 1, 1)).astype(np.float32)
+        sd[f"model.22.cv3.{l}.2.bias"] = np.full(nc, cls_bias, dtype=np.float32)
+    sd["model.22.dfl.conv.weight"] = np.arange(reg_max, dtype=np.float32).reshape(1, reg_max, 1, 1)
+    return sd

@@ -1,0 +1,142 @@
+"""Native YOLOv8 detector backend behind ``TemporalDetector`` (`openglottal/models/detector.py:31,58`).
+
+``YoloV8Detector`` is what ``ultralytics.YOLO(path)`` is to the reference: constructed from a
+weights file, called as ``model(frame_bgr, conf)``.  Differences a user must know:
+
+* weights are a flat ``.npz`` / dict of ultralytics' own state_dict keys (export once, where
+  ultralytics is installed: ``np.savez(out, **{k: v.cpu().numpy() for k, v in
+  YOLO(pt).model.state_dict().items()})``) — an ultralytics ``.pt`` is a pickle of its class graph
+  and cannot be read without the package (SURVEY §7 hard parts);
+* the network arithmetic is restated from ultralytics' published sources: PARITY UNPINNED.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import OpenGlottalHipError, check, lib, ptr
+from .unet import _device_index
+
+STRIDE = 32
+
+
+def letterbox_bgr(frame: np.ndarray, imgsz: int = 256, stride: int = STRIDE):
+    """ultralytics LetterBox(auto=True): fit the long side to ``imgsz``, pad (114) to a stride multiple.
+    Returns ``(img, gain, pad_x, pad_y)``.  Identity for frames whose sides are multiples of 32 and <= imgsz."""
+    from .geometry import resize_linear
+
+    h, w = frame.shape[:2]
+    r = min(imgsz / h, imgsz / w)
+    nw, nh = int(round(w * r)), int(round(h * r))
+    dw, dh = (imgsz - nw) % stride, (imgsz - nh) % stride
+    img = frame if (nw, nh) == (w, h) else resize_linear(frame, nw, nh)
+    top, left = int(round(dh / 2 - 0.1)), int(round(dw / 2 - 0.1))
+    bottom, right = int(round(dh / 2 + 0.1)), int(round(dw / 2 + 0.1))
+    if top or bottom or left or right:
+        img = np.pad(img, ((top, bottom), (left, right), (0, 0)), constant_values=114)
+    return np.ascontiguousarray(img), r, left, top
+
+
+class YoloV8Detector:
+    def __init__(self, weights, nc: int = 1, imgsz: int = 256, device="cuda:0") -> None:
+        if isinstance(weights, (str, os.PathLike)):
+            p = str(weights)
+            if p.endswith(".pt"):
+                raise OpenGlottalHipError(
+                    f"{p}: ultralytics .pt checkpoints are pickles of ultralytics classes; export the state_dict to .npz "
+                    "where ultralytics is installed (see openglottal_amd/yolo.py)")
+            z = np.load(p)
+            weights = {k: z[k] for k in z.files}
+        self.imgsz = imgsz
+        self.nc = nc
+        check(lib().og_init(_device_index(device)), "og_init")
+        h = lib().og_yolo_create(nc)
+        if not h:
+            check(-1, "og_yolo_create")
+        try:
+            for k, v in weights.items():
+                if hasattr(v, "detach"):
+                    v = v.detach().cpu().numpy()
+                v = np.asarray(v)
+                if k.endswith("num_batches_tracked"):
+                    v64 = np.ascontiguousarray(v, dtype=np.int64).reshape(-1)
+                    check(lib().og_yolo_set_tensor(h, k.encode(), ptr(v64), (C.c_int64 * 1)(0), 0, _lib.OG_DTYPE_I64), k)
+                    continue
+                v = np.ascontiguousarray(v, dtype=np.float32)
+                shp = (C.c_int64 * max(1, v.ndim))(*v.shape)
+                check(lib().og_yolo_set_tensor(h, k.encode(), ptr(v), shp, v.ndim, _lib.OG_DTYPE_F32), f"set_tensor({k})")
+            check(lib().og_yolo_finalize(h), "og_yolo_finalize")
+        except Exception:
+            lib().og_yolo_destroy(h)
+            raise
+        self._h = h
+
+    def detect_batch(self, frames_bgr: np.ndarray, conf: float = 0.25, want_pred: bool = False):
+        """``[B,H,W,3]`` u8 BGR at network size (sides multiples of 32) → ``best [B,5]`` (+ ``pred [B,A,5]``)."""
+        f = np.ascontiguousarray(frames_bgr, dtype=np.uint8)
+        B, H, W, _ = f.shape
+        best = np.empty((B, 5), np.float32)
+        A = lib().og_yolo_num_anchors(self._h, H, W)
+        if A < 0:
+            check(A, "og_yolo_num_anchors")
+        pred = np.empty((B, A, 5), np.float32) if want_pred else None
+        check(lib().og_yolo_detect_u8(self._h, ptr(f), B, H, W, float(conf), ptr(best), ptr(pred)), "og_yolo_detect_u8")
+        return (best, pred) if want_pred else best
+
+    def __call__(self, frame_bgr: np.ndarray, conf: float = 0.25):
+        """Backend protocol of ``TemporalDetector``: → ``(xyxy [n,4] f32, conf [n] f32)``, n ∈ {0,1}: the
+        top-confidence detection in ORIGINAL frame pixels (what detector.py:61-64 consumes)."""
+        H0, W0 = frame_bgr.shape[:2]
+        if frame_bgr.ndim == 2:
+            frame_bgr = np.repeat(frame_bgr[..., None], 3, axis=-1)
+        img, gain, px, py = letterbox_bgr(frame_bgr, self.imgsz)
+        b = self.detect_batch(img[None], conf)[0]
+        if b[4] < 0:
+            return np.zeros((0, 4), np.float32), np.zeros(0, np.float32)
+        box = b[:4].copy()
+        if (gain, px, py) != (1.0, 0, 0):  # scale_boxes back to the original frame, then clip
+            box[[0, 2]] = (box[[0, 2]] - px) / gain
+            box[[1, 3]] = (box[[1, 3]] - py) / gain
+        box[[0, 2]] = box[[0, 2]].clip(0, W0)
+        box[[1, 3]] = box[[1, 3]].clip(0, H0)
+        return box[None].astype(np.float32), b[4:5].astype(np.float32)
+
+    def activation(self, name: str, B: int = 1) -> np.ndarray:
+        dims = (C.c_int * 3)()
+        cap = 1 << 22
+        buf = np.empty(cap, np.float32)
+        check(lib().og_yolo_get_activation(self._h, name.encode(), B, ptr(buf), cap, dims), f"og_yolo_get_activation({name})")
+        c, h, w = dims[0], dims[1], dims[2]
+        return buf[: B * c * h * w].reshape(B, c, h, w).copy()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().og_yolo_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def nms(xyxy: np.ndarray, conf: np.ndarray, conf_thres: float = 0.25, iou_thres: float = 0.7, max_det: int = 300) -> np.ndarray:
+    """Greedy single-class NMS over decoded candidates (host side; ultralytics defaults IoU 0.7, 300 dets)."""
+    idx = np.flatnonzero(conf > conf_thres)
+    idx = idx[np.argsort(-conf[idx], kind="stable")]
+    area = (xyxy[:, 2] - xyxy[:, 0]) * (xyxy[:, 3] - xyxy[:, 1])
+    keep = []
+    while idx.size and len(keep) < max_det:
+        i, rest = idx[0], idx[1:]
+        keep.append(i)
+        iw = np.clip(np.minimum(xyxy[i, 2], xyxy[rest, 2]) - np.maximum(xyxy[i, 0], xyxy[rest, 0]), 0, None)
+        ih = np.clip(np.minimum(xyxy[i, 3], xyxy[rest, 3]) - np.maximum(xyxy[i, 1], xyxy[rest, 1]), 0, None)
+        inter = iw * ih
+        idx = rest[inter / (area[i] + area[rest] - inter + 1e-12) <= iou_thres]
+    return np.array(keep, dtype=np.int64)
+
+
+def load_detector_backend(path: str):
+    return YoloV8Detector(path)
