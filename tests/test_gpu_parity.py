@@ -276,3 +276,56 @@ def test_full_size_properties_batch64(full):
     assert np.all(a_lo >= areas[:8]) and np.all(areas[:8] >= a_hi)
     p = 1.0 / (1.0 + np.exp(-logits[:8].astype(np.float64)))
     assert np.all(np.abs(a_hi - (p > 0.7).reshape(8, -1).sum(1)) <= (np.abs(p - 0.7) < 1e-6).reshape(8, -1).sum(1))
+
+
+def test_eval_harness_unet_only_and_scripted_detector(trained):
+    """Counterpart of eval_girafe.evaluate: unet-only row reproduces the reference Dice/IoU of the 80-frame
+    stand-in; yolo+unet / yolo-crop+unet rows with a scripted detector follow their definitions."""
+    from openglottal_amd import evaluate as E
+    g, sd, m, frames, gt = trained
+    patients = [f"p{i // 20}" for i in range(80)]
+    agg, pdice, det = E.evaluate(frames, gt, m, detector=None, patients=patients)
+    s = E.summarize(agg)
+    assert set(s) == {"unet-only"} and s["unet-only"]["n"] == 80
+    assert abs(s["unet-only"]["dice"] - float(g["dice_vs_gt"].mean())) <= 1e-6
+    assert abs(s["unet-only"]["iou"] - float(g["iou_vs_gt"].mean())) <= 1e-6
+    assert sorted(pdice) == ["p0", "p1", "p2", "p3"] and all(len(v["unet-only"]) == 20 for v in pdice.values())
+
+    # scripted detector: box around the image centre on even frames, nothing on odd frames (stateless)
+    calls = {"i": 0}
+
+    def backend(frame, conf):
+        i = calls["i"]
+        calls["i"] += 1
+        if i % 2:
+            return np.zeros((0, 4), np.float32), np.zeros(0, np.float32)
+        return np.array([[88.0, 40.0, 168.0, 216.0]], np.float32), np.array([0.9], np.float32)
+
+    det_ = og.TemporalDetector(backend, padding=0)
+    agg2, _, st = E.evaluate(frames[:20], gt[:20], m, detector=det_, patients=patients[:20], reset_every_frame=True)
+    s2 = E.summarize(agg2)
+    assert s2["yolo+unet"]["det_recall"] == 0.5 and s2["yolo-crop+unet"]["det_recall"] == 0.5
+    masks, _, _ = m.segment(frames[:20])
+    for i in range(20):
+        want = np.zeros_like(masks[i])
+        if i % 2 == 0:
+            want[40:216, 88:168] = masks[i][40:216, 88:168]
+        d, j = og.utils.frame_metrics(want, gt[i])
+        assert agg2["yolo+unet"]["dice"][i] == d and agg2["yolo+unet"]["iou"][i] == j
+    # crop pipeline: 80x176 crop letterboxed to 256 (NEAREST), segmented, projected back: a valid {0,255} mask per frame
+    crop_masks = E.unet_on_crops(frames[:4], [(88, 40, 168, 216), None, (0, 0, 256, 256), (10, 10, 10, 50)], m)
+    assert crop_masks.shape == (4, 256, 256) and set(np.unique(crop_masks)) <= {0, 255}
+    assert not crop_masks[1].any() and not crop_masks[3].any()
+    assert np.array_equal(crop_masks[2], masks[2])            # full-frame "crop" is the identity letterbox
+    assert not crop_masks[0][:40].any() and not crop_masks[0][:, :88].any()
+    E.print_table(agg2)
+
+
+def test_unet_segment_frame_non_256_uses_host_resize(trained):
+    g, sd, m, frames, gt = trained
+    big = np.kron(frames[3], np.ones((2, 2), np.uint8))       # 512x512 frame
+    mk = og.unet_segment_frame(big, m, "cuda:0")
+    assert mk.shape == (512, 512) and set(np.unique(mk)) <= {0, 255}
+    small = og.unet_segment_frame(frames[3], m)
+    # 2x box-upsampled frame -> bilinear down gives the original back -> mask ~ bilinear-up of the probability map
+    assert abs(int((mk > 0).sum()) - 4 * int((small > 0).sum())) <= 0.15 * 4 * max(1, int((small > 0).sum()))
