@@ -94,7 +94,8 @@ def main() -> None:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("OG_BENCH_FORCE_DIST") == "1"  # rehearse the RCCL path on one GPU (world 1)
+    if world > 1 or force_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     feats = (32, 64, 128, 256)
@@ -114,10 +115,10 @@ def main() -> None:
     def step():
         model.segment_dev(frames, F, 256, 256, area)
         model.sync()  # kernels run on the handle's stream; the collective on torch's
-        return all_gather_areas(area, n_total) if world > 1 else area
+        return all_gather_areas(area, n_total, force=force_dist) if (world > 1 or force_dist) else area
 
     def fence():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -168,7 +169,7 @@ def main() -> None:
         out["cpu_baseline"] = cpu_baseline(sd)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

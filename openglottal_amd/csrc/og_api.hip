@@ -104,6 +104,7 @@ struct og_unet {
     int conv_impl = 1;   // 0 = k_conv_mfma (one tile per workgroup), 1 = k_conv_mfma_p (persistent, pipelined)
     int tps_nt1 = 3;     // taps per step for the 32-column kernel
     int tps_nt2 = 1;     // taps per step for the 64-column kernel
+    int prio_mode = 0;   // see ConvArgs::prio_mode
     int wg_per_cu = 2;   // persistent grid = wg_per_cu * CUs (capped by the item count)
     int n_cu = 256;
     std::map<GraphKey, hipGraphExec_t> graphs;
@@ -407,6 +408,7 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     a.res_pix_stride = 0;
     a.res_ch_off = 0;
     const LaunchCtx ctx{h->stream, h->n_cu, h->wg_per_cu};
+    a.prio_mode = h->prio_mode;
     a.stamps = nullptr;
     if (h->prof && h->d_stamps) {  // diagnostic clock stamps, profile runs only
         a.stamps = h->d_stamps + 4 * 1024 * h->prof->size();
@@ -813,6 +815,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "tps_nt1" && (value == 1 || value == 3 || value == 9)) slot = &h->tps_nt1;
     else if (n == "tps_nt2" && (value == 1 || value == 3)) slot = &h->tps_nt2;
     else if (n == "wg_per_cu" && value >= 1 && value <= 2) slot = &h->wg_per_cu;
+    else if (n == "prio_mode" && value >= 0 && value <= 2) slot = &h->prio_mode;
     if (!slot) return fail(OG_EINVAL, "unknown option or bad value: " + n);
     if (*slot != value) {
         if (h->stream) HIPCHK(hipStreamSynchronize(h->stream));
@@ -1055,7 +1058,8 @@ int og_unet_clock_probe(og_unet* h, const uint8_t* gray_dev, int B, int H, int W
         std::vector<double> v;
         for (int w = 0; w < 1024; ++w) {
             const unsigned long long* q = &st[((size_t)i * 1024 + w) * 4];
-            if (q[3] > q[1] && q[2] > q[0]) v.push_back((double)(q[2] - q[0]) / (double)(q[3] - q[1]) * 100.0);
+            const unsigned long long r0 = q[1] & 0xFFFFFFFFFFull, r1 = q[3] & 0xFFFFFFFFFFull;
+            if (r1 > r0 && q[2] > q[0]) v.push_back((double)(q[2] - q[0]) / (double)(r1 - r0) * 100.0);
         }
         if (v.empty()) {
             mhz[i] = 0.0;

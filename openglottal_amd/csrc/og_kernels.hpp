@@ -78,6 +78,7 @@ struct ConvArgs {
     long long res_frame_stride;
     int res_pix_stride;
     int res_ch_off;
+    int prio_mode;          // 0 off; 1/2: alternate s_setprio per unit, role = upper half of the grid / odd block
     unsigned long long* stamps;  // diagnostic only (nullptr in production): per workgroup
                                  // {s_memtime, s_memrealtime} at entry and exit -> in-kernel clock
 };
@@ -371,7 +372,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_p(ConvArgs a, int n_items)
     if (item >= n_items) return;
     if (a.stamps != nullptr && tid == 0) {
         a.stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
-        a.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        // realtime (100 MHz) in the low 40 bits; HW_ID (cu/sh/se/simd...) and XCC_ID above it: lets the probe group workgroups by CU
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);    // HW_REG_HW_ID, 32 bits
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID, low 4 bits
+        a.stamps[4 * blockIdx.x + 1] = (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFFFull) |
+                                       ((unsigned long long)((hw >> 8) & 0xFFFF) << 40) | ((unsigned long long)(xcc & 0xF) << 56);
     }
 
     // cursors
@@ -429,6 +434,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_p(ConvArgs a, int n_items)
 
         for (int c = 0; c < a.n_chunks; ++c) {
             const bool last_unit = last_item && (c + 1 == a.n_chunks);
+            if (a.prio_mode) {
+                // The two workgroups that share a CU do not progress at the same rate (issue arbitration is
+                // priority-then-age): the favoured one finishes ~10 % early and the CU then runs one wave per
+                // SIMD.  Alternating the priority per unit, in opposite phase for the two, evens them out.
+                const int role = (a.prio_mode == 1) ? (int)(blockIdx.x >= (unsigned)(G + 1) / 2) : (int)(blockIdx.x & 1);
+                if ((u + role) & 1)
+                    __builtin_amdgcn_s_setprio(1);
+                else
+                    __builtin_amdgcn_s_setprio(0);
+            }
 #pragma unroll
             for (int s = 0; s < NSTEP_U; ++s) {
                 // ---- issue the prefetches that ride behind this step's MFMAs ----
@@ -553,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_p(ConvArgs a, int n_items)
     }
     if (a.stamps != nullptr && tid == 0) {
         a.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
-        a.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+        a.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFFFull;
     }
 }
 
@@ -725,47 +740,66 @@ __global__ __launch_bounds__(256) void k_conv_direct(const void* __restrict__ in
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      int Cout_p, float* __restrict__ out, long long out_frame_stride,
                                                      int out_pix_stride, int out_ch_off, int Hout, int Wout, int ks, int stride,
-                                                     int pad, int act, int total_pix) {
+                                                     int pad, int act, int total_quads /* B*Hout*ceil(Wout/4) */) {
+    // thread = (4 consecutive output pixels along x) x (4 output channels): 16 accumulators, so one
+    // weight float4 and four input values feed 16 FMAs (the first version did 4 FMAs per 2 loads).
     const int cq = threadIdx.x & 7;
-    const int p = blockIdx.x * 32 + (threadIdx.x >> 3);
-    if (p >= total_pix) return;
-    const int hw = Hout * Wout;
-    const int b = p / hw;
-    const int rem = p - b * hw;
-    const int oy = rem / Wout, ox = rem - oy * Wout;
-    for (int cg = 0; cg < Cout_p; cg += 32) {
-        const int c0 = cg + cq * 4;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int q = blockIdx.x * 32 + (threadIdx.x >> 3);
+    if (q >= total_quads) return;
+    const int qpr = (Wout + 3) >> 2;  // quads per output row
+    const int row = q / qpr;
+    const int ox0 = (q - row * qpr) * 4;
+    const int b = row / Hout;
+    const int oy = row - b * Hout;
+    {
+        const int c0 = blockIdx.y * 32 + cq * 4;  // one 32-channel output group per blockIdx.y: small maps still fill the chip
+        f32x4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int ky = 0; ky < ks; ++ky) {
             const int iy = oy * stride - pad + ky;
             if (iy < 0 || iy >= Hin) continue;
             for (int kx = 0; kx < ks; ++kx) {
-                const int ix = ox * stride - pad + kx;
-                if (ix < 0 || ix >= Win) continue;
                 const float* wp = w + (long long)((ky * ks + kx) * Cin) * Cout_p + c0;
+                int ix[4];
+                bool ok[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ix[j] = (ox0 + j) * stride - pad + kx;
+                    ok[j] = ix[j] >= 0 && ix[j] < Win && (ox0 + j) < Wout;
+                }
                 if (IN_U8) {
-                    const uint8_t* px = (const uint8_t*)in_ + ((long long)b * Hin * Win + (long long)iy * Win + ix) * 3;
+                    const uint8_t* rowp = (const uint8_t*)in_ + ((long long)b * Hin + iy) * Win * 3;
 #pragma unroll
                     for (int ci = 0; ci < 3; ++ci) {
-                        const float xv = (float)px[2 - ci] / 255.0f;  // network channel ci = RGB[ci] = BGR[2-ci]
                         const f32x4 wv = *(const f32x4*)(wp + ci * Cout_p);
-                        acc.x = fmaf(xv, wv.x, acc.x);
-                        acc.y = fmaf(xv, wv.y, acc.y);
-                        acc.z = fmaf(xv, wv.z, acc.z);
-                        acc.w = fmaf(xv, wv.w, acc.w);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float xv = ok[j] ? (float)rowp[ix[j] * 3 + 2 - ci] / 255.0f : 0.f;  // RGB[ci] = BGR[2-ci]
+                            acc[j].x = fmaf(xv, wv.x, acc[j].x);
+                            acc[j].y = fmaf(xv, wv.y, acc[j].y);
+                            acc[j].z = fmaf(xv, wv.z, acc[j].z);
+                            acc[j].w = fmaf(xv, wv.w, acc[j].w);
+                        }
                     }
                 } else {
-                    const float* xp = (const float*)in_ + (long long)b * in_frame_stride + ((long long)iy * Win + ix) * in_pix_stride + in_ch_off;
+                    const float* rowp = (const float*)in_ + (long long)b * in_frame_stride + (long long)iy * Win * in_pix_stride + in_ch_off;
                     for (int ci = 0; ci < Cin; ci += 4) {
-                        const f32x4 xv = *(const f32x4*)(xp + ci);
+                        f32x4 xv[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            xv[j] = ok[j] ? *(const f32x4*)(rowp + (long long)ix[j] * in_pix_stride + ci) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             if (ci + e < Cin) {
                                 const f32x4 wv = *(const f32x4*)(wp + (long long)(ci + e) * Cout_p);
-                                acc.x = fmaf(xv[e], wv.x, acc.x);
-                                acc.y = fmaf(xv[e], wv.y, acc.y);
-                                acc.z = fmaf(xv[e], wv.z, acc.z);
-                                acc.w = fmaf(xv[e], wv.w, acc.w);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    acc[j].x = fmaf(xv[j][e], wv.x, acc[j].x);
+                                    acc[j].y = fmaf(xv[j][e], wv.y, acc[j].y);
+                                    acc[j].z = fmaf(xv[j][e], wv.z, acc[j].z);
+                                    acc[j].w = fmaf(xv[j][e], wv.w, acc[j].w);
+                                }
                             }
                         }
                     }
@@ -774,12 +808,17 @@ __global__ __launch_bounds__(256) void k_conv_direct(const void* __restrict__ in
         }
         const f32x4 sc = *(const f32x4*)(scale + c0);
         const f32x4 sh = *(const f32x4*)(shift + c0);
-        f32x4 o;
-        o.x = og_act(fmaf(acc.x, sc.x, sh.x), act);
-        o.y = og_act(fmaf(acc.y, sc.y, sh.y), act);
-        o.z = og_act(fmaf(acc.z, sc.z, sh.z), act);
-        o.w = og_act(fmaf(acc.w, sc.w, sh.w), act);
-        *(f32x4*)(out + (long long)b * out_frame_stride + ((long long)oy * Wout + ox) * out_pix_stride + out_ch_off + c0) = o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (ox0 + j < Wout) {
+                f32x4 o;
+                o.x = og_act(fmaf(acc[j].x, sc.x, sh.x), act);
+                o.y = og_act(fmaf(acc[j].y, sc.y, sh.y), act);
+                o.z = og_act(fmaf(acc[j].z, sc.z, sh.z), act);
+                o.w = og_act(fmaf(acc[j].w, sc.w, sh.w), act);
+                *(f32x4*)(out + (long long)b * out_frame_stride + ((long long)oy * Wout + ox0 + j) * out_pix_stride + out_ch_off + c0) = o;
+            }
+        }
     }
 }
 

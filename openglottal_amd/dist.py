@@ -26,7 +26,7 @@ def env_rank_world() -> tuple[int, int, int]:
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
 
 
-def all_gather_areas(local, n_frames: int, group=None):
+def all_gather_areas(local, n_frames: int, group=None, force: bool = False):
     """All-gather ragged per-rank area slices into the full ``[n_frames]`` waveform.
 
     ``local``: this rank's areas (torch int32 tensor on the collective's device, or numpy).
@@ -35,7 +35,7 @@ def all_gather_areas(local, n_frames: int, group=None):
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         t = torch.as_tensor(local)
         return t[:n_frames]
     world = dist.get_world_size(group)

@@ -12,10 +12,10 @@ m = og.UNet(1, 1, feats); m.load_state_dict(sd); m.to("cuda:0").eval(); m.set_ch
 F = 256
 frames = torch.from_numpy(synth.bulk_gray_frames(F)).cuda()
 area = torch.zeros(F, dtype=torch.int32, device="cuda")
-variants = {"gen1": dict(conv_impl=0), "p_t1=1,t2=1": dict(conv_impl=1, tps_nt1=1, tps_nt2=1, wg_per_cu=2),
-            "p_t1=3,t2=1": dict(conv_impl=1, tps_nt1=3, tps_nt2=1, wg_per_cu=2),
-            "p_t1=9,t2=1": dict(conv_impl=1, tps_nt1=9, tps_nt2=1, wg_per_cu=2),
-            "p_t1=3,t2=3": dict(conv_impl=1, tps_nt1=3, tps_nt2=3, wg_per_cu=2)}
+variants = {"gen1": dict(conv_impl=0, prio_mode=0),
+            "p_t1=3,t2=1": dict(conv_impl=1, tps_nt1=3, tps_nt2=1, wg_per_cu=2, prio_mode=0),
+            "prio1": dict(conv_impl=1, tps_nt1=3, tps_nt2=1, wg_per_cu=2, prio_mode=1),
+            "prio2": dict(conv_impl=1, tps_nt1=3, tps_nt2=1, wg_per_cu=2, prio_mode=2)}
 res = {k: [] for k in variants}
 for rnd in range(5):
     for name, opts in variants.items():

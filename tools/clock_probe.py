@@ -34,10 +34,25 @@ print("\nper-launch workgroup timeline (us, from s_memrealtime @100MHz)")
 for i, p in enumerate(prof):
     raw = np.zeros((1024, 4), np.uint64)
     check(lib().og_unet_clock_probe_raw(m._h, i, ptr(raw)), "raw")
-    ok = raw[:, 3] > raw[:, 1]
+    M40 = np.uint64(0xFFFFFFFFFF)
+    ok = (raw[:, 3] & M40) > (raw[:, 1] & M40)
     if not ok.any():
         continue
-    r0, r1 = raw[ok, 1].astype(np.float64) / 100.0, raw[ok, 3].astype(np.float64) / 100.0
+    r0, r1 = (raw[ok, 1] & M40).astype(np.float64) / 100.0, (raw[ok, 3] & M40).astype(np.float64) / 100.0
+    cu = (raw[ok, 1] >> np.uint64(40)).astype(np.int64)   # (xcc<<16) | hw_id[23:8]
+    if p["layer"] in ("ups.1.net.0.weight", "downs.1.net.3.weight"):
+        xcc = (cu >> 16) & 0xF
+        busy_ = r1 - r0
+        print("  per-XCC mean busy us:", " ".join(f"x{x}:{busy_[xcc == x].mean():.0f}({(xcc == x).sum()})" for x in sorted(set(xcc.tolist()))))
+        hw = cu & 0xFFFF   # HW_ID[23:8]: cu_id[3:0] sh_id[4] se_id[7:5] ...
+        key = (xcc << 8) | (hw & 0xFF)
+        per = {}
+        for k_, b_ in zip(key.tolist(), busy_.tolist()):
+            per.setdefault(k_, []).append(b_)
+        sizes = sorted(len(v) for v in per.values())
+        spread = [max(v) - min(v) for v in per.values() if len(v) > 1]
+        print(f"  (xcc,se,sh,cu) groups: {len(per)} sizes {sizes[0]}..{sizes[-1]}; within-group spread mean {np.mean(spread):.1f} max {np.max(spread):.1f}; "
+              f"between-group std {np.std([np.mean(v) for v in per.values()]):.1f}")
     span = r1.max() - r0.min()
     busy = (r1 - r0)
     print(f"{p['layer']:26s} wgs={ok.sum():4d} span={span:7.1f}us event_ms={p['ms']*1e3:7.1f}us start_skew(max)={r0.max()-r0.min():6.1f} "
