@@ -105,6 +105,8 @@ struct og_unet {
     int tps_nt1 = 3;     // taps per step for the 32-column kernel
     int tps_nt2 = 1;     // taps per step for the 64-column kernel
     int prio_mode = 0;   // see ConvArgs::prio_mode
+    int splitk = 1;      // allow split-K on launches that would fill < 1/4 of the chip (latency mode)
+    float* d_partial = nullptr;
     int wg_per_cu = 2;   // persistent grid = wg_per_cu * CUs (capped by the item count)
     int n_cu = 256;
     std::map<GraphKey, hipGraphExec_t> graphs;
@@ -332,15 +334,33 @@ struct LaunchCtx {
     int wg_per_cu;
 };
 
+constexpr size_t kPartialBytes = 64u << 20;  // split-K workspace (only small launches ever use it)
+
+// Split-K factor for a launch of `n_items` tiles over `n_chunks` 32-channel chunks: only when the
+// launch would leave >= 3/4 of the workgroup slots empty (small-batch / latency mode), so that
+// throughput-mode results do not depend on the micro-batch size.
+inline int pick_ksplit(int n_items, int n_chunks, int slots, int ms, bool enable) {
+    if (!enable || n_chunks < 2 || n_items * 4 > slots) return 1;
+    int k = slots / n_items;
+    if (k > n_chunks) k = n_chunks;
+    const size_t per_item = (size_t)4 * ms * 16 * 64 * sizeof(float);
+    while (k > 1 && (size_t)n_items * k * per_item > kPartialBytes) --k;
+    return k < 1 ? 1 : k;
+}
+
 template <int NT, int MODE, int TH, int TPS>
 int launch_conv_p(const LaunchCtx& c, const ConvArgs& a, int n_ntiles) {
     constexpr int lds = conv_p_lds<NT, MODE, TH, TPS>();
-    const int n_items = a.n_spatial * n_ntiles;
+    const int n_items = a.n_spatial * n_ntiles * a.ksplit;
     const int slots = c.n_cu * ((lds > 80 * 1024) ? 1 : c.wg_per_cu);
     const int rounds = (n_items + slots - 1) / slots;
     const int grid = (n_items + rounds - 1) / rounds;  // <= slots, balanced: every workgroup gets rounds or rounds-1 items
     hipLaunchKernelGGL((k_conv_mfma_p<NT, MODE, TH, TPS>), dim3(grid), dim3(256), lds, c.stream, a, n_items);
     HIPCHK(hipGetLastError());
+    if (a.ksplit > 1) {
+        hipLaunchKernelGGL((k_splitk_epilogue<NT, MODE, TH>), dim3(a.n_spatial * n_ntiles), dim3(256), 0, c.stream, a);
+        HIPCHK(hipGetLastError());
+    }
     return OG_OK;
 }
 
@@ -409,6 +429,13 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     a.res_ch_off = 0;
     const LaunchCtx ctx{h->stream, h->n_cu, h->wg_per_cu};
     a.prio_mode = h->prio_mode;
+    a.ksplit = 1;
+    a.partial = h->d_partial;
+    if (h->conv_impl == 1) {
+        const int nt = (L.mode == 0) ? L.Cout_p / (32 * L.NT) : 4 * L.Cout_p / 64;
+        const int ms = (L.NT == 2) ? 2 : 1;
+        a.ksplit = pick_ksplit(a.n_spatial * nt, a.n_chunks, h->n_cu * h->wg_per_cu, ms, h->splitk != 0 && h->d_partial != nullptr);
+    }
     a.stamps = nullptr;
     if (h->prof && h->d_stamps) {  // diagnostic clock stamps, profile runs only
         a.stamps = h->d_stamps + 4 * 1024 * h->prof->size();
@@ -679,6 +706,7 @@ void og_unet_destroy(og_unet* h) {
     if (h->arena) (void)hipFree(h->arena);
     if (h->stage) (void)hipFree(h->stage);
     if (h->d_stamps) (void)hipFree(h->d_stamps);
+    if (h->d_partial) (void)hipFree(h->d_partial);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -736,6 +764,7 @@ int og_unet_finalize(og_unet* h) {
     HIPCHK(hipEventCreate(&h->ev1));
     HIPCHK(hipMalloc((void**)&h->d_zero, 4096));
     HIPCHK(hipMemset(h->d_zero, 0, 4096));
+    HIPCHK(hipMalloc((void**)&h->d_partial, kPartialBytes));
 
     const int L = h->L;
     int rc;
@@ -816,6 +845,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "tps_nt2" && (value == 1 || value == 3)) slot = &h->tps_nt2;
     else if (n == "wg_per_cu" && value >= 1 && value <= 2) slot = &h->wg_per_cu;
     else if (n == "prio_mode" && value >= 0 && value <= 2) slot = &h->prio_mode;
+    else if (n == "splitk" && (value == 0 || value == 1)) slot = &h->splitk;
     if (!slot) return fail(OG_EINVAL, "unknown option or bad value: " + n);
     if (*slot != value) {
         if (h->stream) HIPCHK(hipStreamSynchronize(h->stream));

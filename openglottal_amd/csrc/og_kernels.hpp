@@ -78,6 +78,8 @@ struct ConvArgs {
     long long res_frame_stride;
     int res_pix_stride;
     int res_ch_off;
+    int ksplit;             // >1: split-K.  Item = (tile, K-range); raw accumulators go to `partial`, and
+    float* partial;         // k_splitk_epilogue sums them in split order and runs the epilogue (small-batch latency mode)
     int prio_mode;          // 0 off; 1/2: alternate s_setprio per unit, role = upper half of the grid / odd block
     unsigned long long* stamps;  // diagnostic only (nullptr in production): per workgroup
                                  // {s_memtime, s_memrealtime} at entry and exit -> in-kernel clock
@@ -262,6 +264,57 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
     }
 }
 
+// Shared epilogue of k_conv_mfma_p / k_splitk_epilogue: per-channel affine, activation, optional
+// residual, NHWC store (scattered for the transposed conv), optional fused 2x2 max-pool.
+template <int NT, int MODE, int TH>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16* acc, int n_tile, int b, int ty0, int tx0, int wm, int wn,
+                                              int li, int lh, float sc, float sh) {
+    constexpr int WROWS = 32 * NT;
+    constexpr int WM = 4 / NT;
+    constexpr int MS = (TH / 2) / WM;
+    const int ncol = n_tile * WROWS + wn * 32 + li;
+    int co = ncol, qd = 0;
+    if (MODE == 1) {
+        qd = ncol / a.aff_mod;
+        co = ncol - qd * a.aff_mod;
+    }
+    const int OW = (MODE == 1) ? 2 * a.W : a.W;
+    float* out_frame = a.out + (long long)b * a.out_frame_stride + a.out_ch_off + co;
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+        const int ms = wm * MS + m;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int wdw = 2 * g + lh;
+            float vmax = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float v = fmaf(acc[m][4 * g + rr], sc, sh);
+                v = og_act(v, a.act);
+                const int y = ty0 + 2 * ms + (rr >> 1);
+                const int x = tx0 + 2 * wdw + (rr & 1);
+                if (y < a.H && x < a.W) {
+                    if (MODE != 1) {
+                        if (a.res != nullptr)
+                            v += a.res[(long long)b * a.res_frame_stride + ((long long)y * OW + x) * a.res_pix_stride + a.res_ch_off + co];
+                        out_frame[((long long)y * OW + x) * a.out_pix_stride] = v;
+                    } else {
+                        out_frame[((long long)(2 * y + (qd >> 1)) * OW + (2 * x + (qd & 1))) * a.out_pix_stride] = v;
+                    }
+                }
+                vmax = (rr == 0) ? v : fmaxf(vmax, v);
+            }
+            if (MODE == 0 && a.pool != nullptr) {
+                const int y = ty0 + 2 * ms, x = tx0 + 2 * wdw;
+                if (y < a.H && x < a.W) {
+                    float* pf = a.pool + (long long)b * a.pool_frame_stride + a.pool_ch_off + co;
+                    pf[((long long)(y >> 1) * (a.W >> 1) + (x >> 1)) * a.pool_pix_stride] = vmax;
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Generation 2 of the implicit-GEMM conv: PERSISTENT workgroups walking a flat sequence of
 // (item = (n_tile, frame, spatial tile), 32-channel chunk, tap-group) steps.
@@ -309,9 +362,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_p(ConvArgs a, int n_items)
     const int G = gridDim.x;
     const int tiles_per_frame = a.tiles_x * a.tiles_y;
 
+    // item -> (K-split, n_tile, frame, tile); chunk range of a split: [c_lo, c_hi)
+    const int ks_n = a.ksplit;
+    auto c_lo = [&](int item) { return (ks_n == 1) ? 0 : ((item % ks_n) * a.n_chunks) / ks_n; };
+    auto c_hi = [&](int item) { return (ks_n == 1) ? a.n_chunks : ((item % ks_n + 1) * a.n_chunks) / ks_n; };
     auto decode = [&](int item, int& n_tile, int& b, int& ty0, int& tx0) {
-        n_tile = item / a.n_spatial;
-        int sp = item - n_tile * a.n_spatial;
+        const int base = (ks_n == 1) ? item : item / ks_n;
+        n_tile = base / a.n_spatial;
+        int sp = base - n_tile * a.n_spatial;
         b = sp / tiles_per_frame;
         sp -= b * tiles_per_frame;
         const int tyi = sp / a.tiles_x;
@@ -380,33 +438,38 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_p(ConvArgs a, int n_items)
     }
 
     // cursors
-    int h_item = item, h_c = 0;           // next halo unit to stage
-    int w_item = item, w_c = 0, w_s = 0;  // next weight step to stage
-    int w_ntile = item / a.n_spatial;
+    int h_item = item, h_c = c_lo(item);           // next halo unit to stage
+    int w_item = item, w_c = c_lo(item), w_s = 0;  // next weight step to stage
+    auto ntile_of = [&](int it) { return ((ks_n == 1) ? it : it / ks_n) / a.n_spatial; };
+    int w_ntile = ntile_of(item);
     set_hsrc(h_item);
 
     auto adv_h = [&]() {
-        if (++h_c == a.n_chunks) {
-            h_c = 0;
+        if (++h_c == c_hi(h_item)) {
             h_item += G;
-            if (h_item < n_items) set_hsrc(h_item);
+            if (h_item < n_items) {
+                h_c = c_lo(h_item);
+                set_hsrc(h_item);
+            }
         }
     };
     auto adv_w = [&]() {
         if (++w_s == NSTEP_U) {
             w_s = 0;
-            if (++w_c == a.n_chunks) {
-                w_c = 0;
+            if (++w_c == c_hi(w_item)) {
                 w_item += G;
-                w_ntile = w_item / a.n_spatial;
+                if (w_item < n_items) {
+                    w_c = c_lo(w_item);
+                    w_ntile = ntile_of(w_item);
+                }
             }
         }
     };
 
     // prologue: unit 0 halo, step 0 weights
-    stage_halo(0, 0);
+    stage_halo(0, h_c);
     adv_h();
-    stage_w(0, w_ntile, 0, 0);
+    stage_w(0, w_ntile, w_c, 0);
     adv_w();
     og_wait_dma();
     __syncthreads();
@@ -432,8 +495,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_p(ConvArgs a, int n_items)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-        for (int c = 0; c < a.n_chunks; ++c) {
-            const bool last_unit = last_item && (c + 1 == a.n_chunks);
+        const int c_end = c_hi(item);
+        for (int c = c_lo(item); c < c_end; ++c) {
+            const bool last_unit = last_item && (c + 1 == c_end);
             if (a.prio_mode) {
                 // The two workgroups that share a CU do not progress at the same rate (issue arbitration is
                 // priority-then-age): the favoured one finishes ~10 % early and the CU then runs one wave per
@@ -517,52 +581,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_p(ConvArgs a, int n_items)
             ++u;
         }
 
-        // ---- epilogue: affine (+ReLU), store, optional fused 2x2 max-pool ----
-        const int ncol = n_tile * WROWS + wn * 32 + li;
-        int co = ncol, qd = 0;
-        if (MODE == 1) {
-            qd = ncol / a.aff_mod;
-            co = ncol - qd * a.aff_mod;
-        }
-        if (n_tile != cached_ntile) {  // ordinary loads drain the LDS-DMA queue: keep them rare
-            sc = a.scale[co];
-            sh = a.shift[co];
-            cached_ntile = n_tile;
-        }
-        const int OW = (MODE == 1) ? 2 * a.W : a.W;
-        float* out_frame = a.out + (long long)b * a.out_frame_stride + a.out_ch_off + co;
+        // ---- epilogue ----
+        if (ks_n > 1) {
+            // split-K: raw accumulators, register order, lane-contiguous (256-B stores); summed by k_splitk_epilogue
+            float* pw = a.partial + ((long long)item * 4 + wave) * (MS * 16 * 64) + lane;
 #pragma unroll
-        for (int m = 0; m < MS; ++m) {
-            const int ms = wm * MS + m;
+            for (int m = 0; m < MS; ++m)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int wdw = 2 * g + lh;
-                float vmax = 0.f;
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    float v = fmaf(acc[m][4 * g + rr], sc, sh);
-                    v = og_act(v, a.act);
-                    const int y = ty0 + 2 * ms + (rr >> 1);
-                    const int x = tx0 + 2 * wdw + (rr & 1);
-                    if (y < a.H && x < a.W) {
-                        if (MODE != 1) {
-                            if (a.res != nullptr)
-                                v += a.res[(long long)b * a.res_frame_stride + ((long long)y * OW + x) * a.res_pix_stride + a.res_ch_off + co];
-                            out_frame[((long long)y * OW + x) * a.out_pix_stride] = v;
-                        } else {
-                            out_frame[((long long)(2 * y + (qd >> 1)) * OW + (2 * x + (qd & 1))) * a.out_pix_stride] = v;
-                        }
-                    }
-                    vmax = (rr == 0) ? v : fmaxf(vmax, v);
-                }
-                if (MODE == 0 && a.pool != nullptr) {
-                    const int y = ty0 + 2 * ms, x = tx0 + 2 * wdw;
-                    if (y < a.H && x < a.W) {
-                        float* pf = a.pool + (long long)b * a.pool_frame_stride + a.pool_ch_off + co;
-                        pf[((long long)(y >> 1) * (a.W >> 1) + (x >> 1)) * a.pool_pix_stride] = vmax;
-                    }
-                }
+                for (int r = 0; r < 16; ++r) pw[(m * 16 + r) * 64] = acc[m][r];
+        } else {
+            if (n_tile != cached_ntile) {  // ordinary loads drain the LDS-DMA queue: keep them rare
+                const int ncol = n_tile * WROWS + wn * 32 + li;
+                const int co = (MODE == 1) ? ncol % a.aff_mod : ncol;
+                sc = a.scale[co];
+                sh = a.shift[co];
+                cached_ntile = n_tile;
             }
+            conv_epilogue<NT, MODE, TH>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, sc, sh);
         }
         item += G;
     }
@@ -570,6 +605,43 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_p(ConvArgs a, int n_items)
         a.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
         a.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFFFull;
     }
+}
+
+// Second pass of split-K: one workgroup per (n_tile, frame, tile), same thread roles as the conv
+// kernel; sums the K-split partials IN SPLIT ORDER (deterministic) and runs the shared epilogue.
+template <int NT, int MODE, int TH>
+__global__ __launch_bounds__(256) void k_splitk_epilogue(ConvArgs a) {
+    constexpr int TW = 16;
+    constexpr int WROWS = 32 * NT;
+    constexpr int WM = 4 / NT;
+    constexpr int MS = (TH / 2) / WM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % NT, wm = wave / NT, li = lane & 31, lh = lane >> 5;
+    const int base = blockIdx.x;
+    const int n_tile = base / a.n_spatial;
+    int sp = base - n_tile * a.n_spatial;
+    const int tiles_per_frame = a.tiles_x * a.tiles_y;
+    const int b = sp / tiles_per_frame;
+    sp -= b * tiles_per_frame;
+    const int tyi = sp / a.tiles_x;
+    const int ty0 = tyi * TH, tx0 = (sp - tyi * a.tiles_x) * TW;
+    f32x16 acc[MS];
+#pragma unroll
+    for (int m = 0; m < MS; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    for (int s = 0; s < a.ksplit; ++s) {
+        const float* pw = a.partial + (((long long)base * a.ksplit + s) * 4 + wave) * (MS * 16 * 64) + lane;
+#pragma unroll
+        for (int m = 0; m < MS; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] += pw[(m * 16 + r) * 64];
+    }
+    const int ncol = n_tile * WROWS + wn * 32 + li;
+    const int co = (MODE == 1) ? ncol % a.aff_mod : ncol;
+    conv_epilogue<NT, MODE, TH>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, a.scale[co], a.shift[co]);
 }
 
 // First layer: Conv2d(1, f0, 3, pad 1) + BN + ReLU straight from the u8 frame

@@ -160,6 +160,7 @@ def test_chunking_and_graphs_are_result_invariant(trained):
     g, sd, m, frames, gt = trained
     fr = frames[:37]  # ragged: not a multiple of any chunk below
     base = None
+    m.set_option("splitk", 0)  # split-K (small launches only) changes the summation order: covered by its own test
     for chunk, graphs in [(16, True), (1, True), (5, False), (64, True), (16, False)]:
         m.set_chunk(chunk)
         m.set_graphs(graphs)
@@ -169,9 +170,37 @@ def test_chunking_and_graphs_are_result_invariant(trained):
         else:
             assert np.array_equal(masks, base[0]) and np.array_equal(areas, base[1]), (chunk, graphs)
             assert np.array_equal(logits, base[2]), (chunk, graphs)  # same kernels, same order: bit-identical
-    m.set_chunk(16)
+    m.set_chunk(32)
     m.set_graphs(True)
+    m.set_option("splitk", 1)
     assert np.array_equal(base[1].astype(np.int64), g["areas"][:37])
+
+
+def test_split_k_latency_mode(trained, full):
+    """Small launches (batch 1..4) split K over workgroups and reduce in a fixed order: deterministic,
+    within fp32 re-association noise of the unsplit path, and still bit-exact on the trained fixture."""
+    g, sd, m, frames, gt = trained
+    m.set_option("splitk", 1)
+    for B in (1, 2, 3):
+        m.set_chunk(B)
+        masks, areas, logits = m.segment(frames[:6], want_logits=True)
+        masks2, areas2, logits2 = m.segment(frames[:6], want_logits=True)
+        assert np.array_equal(logits, logits2) and np.array_equal(areas, areas2)      # deterministic
+        assert np.array_equal(areas.astype(np.int64), g["areas"][:6])
+        assert np.array_equal(masks > 0, np.stack([unpack(b) for b in g["masks_packed"][:6]]) > 0)
+    gf, sdf, mf, framesf, gtf = full
+    mf.set_chunk(1)
+    mf.set_option("splitk", 1)
+    _, a1, l1 = mf.segment(framesf, want_mask=False, want_logits=True)
+    mf.set_option("splitk", 0)
+    _, a0, l0 = mf.segment(framesf, want_mask=False, want_logits=True)
+    mf.set_option("splitk", 1)
+    mf.set_chunk(32)
+    m.set_chunk(32)
+    assert not np.array_equal(l0, l1)                                                 # the split path really ran
+    assert np.abs(l0 - l1).max() <= TOL
+    assert np.abs(l1.reshape(8, -1)[:, gf["sample_idx"]] - gf["logits_samples"]).max() <= TOL
+    assert np.all(np.abs(a0.astype(int) - a1.astype(int)) <= ((l0 > 0) != (l1 > 0)).reshape(8, -1).sum(1))
 
 
 def test_kernel_variants_bit_identical(full):
@@ -179,6 +208,7 @@ def test_kernel_variants_bit_identical(full):
     accumulation order per output element -> bit-identical logits."""
     g, sd, m, frames, gt = full
     fr = frames[:5]
+    m.set_option("splitk", 0)
     m.set_option("conv_impl", 0)
     _, a0, l0 = m.segment(fr, want_mask=False, want_logits=True)
     try:
@@ -194,6 +224,7 @@ def test_kernel_variants_bit_identical(full):
         m.set_option("tps_nt1", 3)
         m.set_option("tps_nt2", 1)
         m.set_option("wg_per_cu", 2)
+        m.set_option("splitk", 1)
 
 
 def test_empty_batch_and_bad_shapes(trained):
