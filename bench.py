@@ -37,6 +37,25 @@ def host_cores() -> int:
     return n
 
 
+def pmc_traffic(kernel: str, frames_per_launch: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*pmc_traffic*.json,
+    produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command)."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_traffic_chunk{frames_per_launch}.json"))):
+        best = path
+    if best is None:
+        return None
+    d = json.load(open(best))
+    want = kernel.replace(",", ", ")
+    for name, v in d.items():
+        if want in name:
+            return {"hbm_bytes_per_launch": round(v["hbm_bytes_per_launch"]), "read": round(v["read_bytes_per_launch"]),
+                    "write": round(v["write_bytes_per_launch"]), "source": os.path.basename(best)}
+    return None
+
+
 def cpu_baseline(sd, budget_s: float = 12.0, max_frames: int = 256):
     """Reference loop semantics (one frame per call, batch 1) on the host cores, timed on the
     oracle's torch-CPU restatement (same oneDNN kernels the reference runs)."""
@@ -74,7 +93,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=512, help="frames per GPU per step (weak scaling)")
-    ap.add_argument("--chunk", type=int, default=32, help="frames per kernel chain (micro-batch of the frame loop)")
+    ap.add_argument("--chunk", type=int, default=64, help="frames per kernel chain (micro-batch of the frame loop)")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -158,7 +177,7 @@ def main() -> None:
         tot_ms = sum(p["ms"] for p in prof)
         ach = fl / (ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(DOMINANT, B),
                            "launches_per_chain": len(dom), "avg_launch_ms": round(ms / len(dom), 4),
                            "share_of_chain_time": round(ms / tot_ms, 3), "frames_per_launch": B,
                            "chain_ms": round(tot_ms, 3)}

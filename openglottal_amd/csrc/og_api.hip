@@ -104,7 +104,8 @@ struct og_unet {
     int conv_impl = 1;   // 0 = k_conv_mfma (one tile per workgroup), 1 = k_conv_mfma_p (persistent, pipelined)
     int tps_nt1 = 3;     // taps per step for the 32-column kernel
     int tps_nt2 = 1;     // taps per step for the 64-column kernel
-    int prio_mode = 0;   // see ConvArgs::prio_mode
+    int prio_mode = 2;   // see ConvArgs::prio_mode (measured +1.2 % on the frame loop)
+    int tile_h = 8;      // 8: 8x16-pixel tiles, two workgroups per CU; 16: 16x16 tiles, one workgroup per CU
     int splitk = 1;      // allow split-K on launches that would fill < 1/4 of the chip (latency mode)
     float* d_partial = nullptr;
     int wg_per_cu = 2;   // persistent grid = wg_per_cu * CUs (capped by the item count)
@@ -390,6 +391,10 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     if ((rc = set_conv_p_attr<1, 0, 8, 3>())) return rc;
     if ((rc = set_conv_p_attr<1, 0, 8, 9>())) return rc;
     if ((rc = set_conv_p_attr<2, 1, 8, 1>())) return rc;
+    if ((rc = set_conv_p_attr<2, 0, 16, 1>())) return rc;
+    if ((rc = set_conv_p_attr<2, 0, 16, 3>())) return rc;
+    if ((rc = set_conv_p_attr<1, 0, 16, 3>())) return rc;
+    if ((rc = set_conv_p_attr<1, 0, 16, 9>())) return rc;
     if ((rc = set_conv_p_attr<2, 2, 8, 1>())) return rc;
     if ((rc = set_conv_p_attr<1, 2, 8, 1>())) return rc;
     return OG_OK;
@@ -398,6 +403,9 @@ int init_kernel_attrs() {  // must not run inside a stream capture
 // in: activation view + channel offset/count; out likewise; pool optional
 int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off, const Act& out, int out_off, const Act* pool) {
     constexpr int TH = 8;
+    // 16x16 tiles only for the 3x3 convs of the persistent kernel, and only when every tile is full
+    const bool big = (h->conv_impl == 1 && h->tile_h == 16 && L.mode == 0 && in.H % 16 == 0 && in.W % 16 == 0);
+    const int th = big ? 16 : 8;
     ConvArgs a;
     a.in = in.p;
     a.in_frame_stride = in.frame_stride();
@@ -407,7 +415,7 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     a.H = in.H;
     a.W = in.W;
     a.tiles_x = (in.W + 15) / 16;
-    a.tiles_y = (in.H + TH - 1) / TH;
+    a.tiles_y = (in.H + th - 1) / th;
     a.n_spatial = B * a.tiles_x * a.tiles_y;
     a.wpk = L.d_w;
     a.scale = L.d_scale;
@@ -433,7 +441,7 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     a.partial = h->d_partial;
     if (h->conv_impl == 1) {
         const int nt = (L.mode == 0) ? L.Cout_p / (32 * L.NT) : 4 * L.Cout_p / 64;
-        const int ms = (L.NT == 2) ? 2 : 1;
+        const int ms = ((L.NT == 2) ? 2 : 1) * (big ? 2 : 1);
         a.ksplit = pick_ksplit(a.n_spatial * nt, a.n_chunks, h->n_cu * h->wg_per_cu, ms, h->splitk != 0 && h->d_partial != nullptr);
     }
     a.stamps = nullptr;
@@ -449,6 +457,24 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         if (h->conv_impl == 0) {
             prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma<2,0,8>" : "k_conv_mfma<1,0,8>", fl);
             rc = (L.NT == 2) ? launch_conv_t<2, 0, TH>(h, a, n_ntiles) : launch_conv_t<1, 0, TH>(h, a, n_ntiles);
+        } else if (big && L.NT == 2) {
+            a.ksplit = 1;
+            if (h->tps_nt2 == 3) {
+                prof_begin(h, L.name, "k_conv_mfma_p<2,0,16,3>", fl);
+                rc = launch_conv_p<2, 0, 16, 3>(ctx, a, n_ntiles);
+            } else {
+                prof_begin(h, L.name, "k_conv_mfma_p<2,0,16,1>", fl);
+                rc = launch_conv_p<2, 0, 16, 1>(ctx, a, n_ntiles);
+            }
+        } else if (big) {
+            a.ksplit = 1;
+            if (h->tps_nt1 == 9) {
+                prof_begin(h, L.name, "k_conv_mfma_p<1,0,16,9>", fl);
+                rc = launch_conv_p<1, 0, 16, 9>(ctx, a, n_ntiles);
+            } else {
+                prof_begin(h, L.name, "k_conv_mfma_p<1,0,16,3>", fl);
+                rc = launch_conv_p<1, 0, 16, 3>(ctx, a, n_ntiles);
+            }
         } else if (L.NT == 2) {
             if (h->tps_nt2 == 3) {
                 prof_begin(h, L.name, "k_conv_mfma_p<2,0,8,3>", fl);
@@ -846,6 +872,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "wg_per_cu" && value >= 1 && value <= 2) slot = &h->wg_per_cu;
     else if (n == "prio_mode" && value >= 0 && value <= 2) slot = &h->prio_mode;
     else if (n == "splitk" && (value == 0 || value == 1)) slot = &h->splitk;
+    else if (n == "tile_h" && (value == 8 || value == 16)) slot = &h->tile_h;
     if (!slot) return fail(OG_EINVAL, "unknown option or bad value: " + n);
     if (*slot != value) {
         if (h->stream) HIPCHK(hipStreamSynchronize(h->stream));

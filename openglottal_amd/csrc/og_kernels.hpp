@@ -328,7 +328,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16* a
 // Same arithmetic, same accumulation order per output element as k_conv_mfma (results are
 // bit-identical between the two).  MODE 2 (this kernel only): 1x1 conv, no halo, plain epilogue.
 template <int NT, int MODE, int TH, int TPS>
-__global__ __launch_bounds__(256, 2) void k_conv_mfma_p(ConvArgs a, int n_items) {
+__global__ __launch_bounds__(256, (TH >= 16) ? 1 : 2) void k_conv_mfma_p(ConvArgs a, int n_items) {
     constexpr int TW = 16;
     constexpr int PAD = (MODE == 0) ? 1 : 0;
     constexpr int HW_ = TW + 2 * PAD;

@@ -360,3 +360,22 @@ def test_unet_segment_frame_non_256_uses_host_resize(trained):
     small = og.unet_segment_frame(frames[3], m)
     # 2x box-upsampled frame -> bilinear down gives the original back -> mask ~ bilinear-up of the probability map
     assert abs(int((mk > 0).sum()) - 4 * int((small > 0).sum())) <= 0.15 * 4 * max(1, int((small > 0).sum()))
+
+
+def test_large_frames_and_large_ragged_batch(trained):
+    """Maximum-size style cases: a 512x384 frame (tiles beyond 256, non-square) against the oracle, and a
+    ragged 203-frame batch whose per-frame results must repeat the 80-frame golden areas exactly."""
+    from oracle import unet_oracle as O
+    feats = (4, 8)
+    sd2 = synth.make_unet_state_dict(feats, seed=77, head_scale=2.5, head_bias=-0.2)
+    m2 = make_model(sd2, feats)
+    fr = synth.random_gray_frames(2, 384, 512, seed=123)
+    ref_mask, ref_logits = O.segment_frames(sd2, fr, backend="torch")
+    masks, areas, logits = m2.segment(fr, want_logits=True)
+    assert np.abs(logits - ref_logits).max() <= TOL * max(1.0, np.abs(ref_logits).max())
+    diff = (masks > 0) != (ref_mask > 0)
+    assert np.all(np.abs(ref_logits[diff]) <= TOL)
+    g, sd, m, frames, gt = trained
+    idx = np.arange(203) % 80
+    _, areas, _ = m.segment(frames[idx], want_mask=False)
+    assert np.array_equal(areas.astype(np.int64), g["areas"][idx])
