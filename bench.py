@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = f32 vector peak
-DOMINANT = "k_conv_mfma_p<2,0,8,1>"
+DOMINANT = "k_conv_mfma_o<2,0,16>"  # the 64-column 3x3 conv on 16x16 tiles: largest share of chain time
 
 
 def host_cores() -> int:
@@ -48,7 +48,7 @@ def pmc_traffic(kernel: str, frames_per_launch: int):
     if best is None:
         return None
     d = json.load(open(best))
-    want = kernel.replace(",", ", ")
+    want = kernel.replace(",", ", ").replace(">", "")  # rocprof prints all template args, e.g. "<2, 0, 16, 2>"
     for name, v in d.items():
         if want in name:
             return {"hbm_bytes_per_launch": round(v["hbm_bytes_per_launch"]), "read": round(v["read_bytes_per_launch"]),

@@ -101,11 +101,13 @@ struct og_unet {
     unsigned long long* d_stamps = nullptr;  // [64 launches][1024 workgroups][4], allocated by og_unet_clock_probe
     int chunk = 32;
     int use_graphs = 1;
-    int conv_impl = 1;   // 0 = k_conv_mfma (one tile per workgroup), 1 = k_conv_mfma_p (persistent, pipelined)
+    int conv_impl = 2;   // 0 k_conv_mfma | 1 k_conv_mfma_p (persistent, pipelined) | 2 auto: k_conv_mfma_o (3 WG/CU, single halo
+                         // buffer) for full launches, k_conv_mfma_p + split-K for launches that cannot fill the chip | 3 k_conv_mfma_o, 4 WG/CU
     int tps_nt1 = 3;     // taps per step for the 32-column kernel
     int tps_nt2 = 1;     // taps per step for the 64-column kernel
     int prio_mode = 2;   // see ConvArgs::prio_mode (measured +1.2 % on the frame loop)
-    int tile_h = 8;      // 8: 8x16-pixel tiles, two workgroups per CU; 16: 16x16 tiles, one workgroup per CU
+    int convt_occ = 1;   // with conv_impl >= 2: run the transposed convs on the occupancy variant too
+    int tile_h = 0;      // 0 auto (16x16 tiles for 64-channel-tile layers at <= 64x64 pixels, else 8x16) | 8 | 16
     int splitk = 1;      // allow split-K on launches that would fill < 1/4 of the chip (latency mode)
     float* d_partial = nullptr;
     int wg_per_cu = 2;   // persistent grid = wg_per_cu * CUs (capped by the item count)
@@ -349,6 +351,15 @@ inline int pick_ksplit(int n_items, int n_chunks, int slots, int ms, bool enable
     return k < 1 ? 1 : k;
 }
 
+template <int NT, int MODE, int TH, int OCC>
+int launch_conv_o(const LaunchCtx& c, const ConvArgs& a, int n_ntiles) {
+    constexpr int PAD = (MODE == 0) ? 1 : 0;
+    constexpr int lds = (16 + 2 * PAD) * (TH + 2 * PAD) * 128 + 2 * 32 * NT * 128;
+    hipLaunchKernelGGL((k_conv_mfma_o<NT, MODE, TH, OCC>), dim3(a.n_spatial * n_ntiles), dim3(256), lds, c.stream, a);
+    HIPCHK(hipGetLastError());
+    return OG_OK;
+}
+
 template <int NT, int MODE, int TH, int TPS>
 int launch_conv_p(const LaunchCtx& c, const ConvArgs& a, int n_ntiles) {
     constexpr int lds = conv_p_lds<NT, MODE, TH, TPS>();
@@ -391,6 +402,13 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     if ((rc = set_conv_p_attr<1, 0, 8, 3>())) return rc;
     if ((rc = set_conv_p_attr<1, 0, 8, 9>())) return rc;
     if ((rc = set_conv_p_attr<2, 1, 8, 1>())) return rc;
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 18 * 128 + 2 * 64 * 128));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 16, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 18 * 128 + 2 * 32 * 128));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 1, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8 * 128 + 2 * 64 * 128));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 10 * 128 + 2 * 64 * 128));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 10 * 128 + 2 * 32 * 128));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 10 * 128 + 2 * 64 * 128));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 10 * 128 + 2 * 32 * 128));
     if ((rc = set_conv_p_attr<2, 0, 16, 1>())) return rc;
     if ((rc = set_conv_p_attr<2, 0, 16, 3>())) return rc;
     if ((rc = set_conv_p_attr<1, 0, 16, 3>())) return rc;
@@ -404,7 +422,11 @@ int init_kernel_attrs() {  // must not run inside a stream capture
 int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off, const Act& out, int out_off, const Act* pool) {
     constexpr int TH = 8;
     // 16x16 tiles only for the 3x3 convs of the persistent kernel, and only when every tile is full
-    const bool big = (h->conv_impl == 1 && h->tile_h == 16 && L.mode == 0 && in.H % 16 == 0 && in.W % 16 == 0);
+    const bool full16 = (L.mode == 0 && in.H % 16 == 0 && in.W % 16 == 0);
+    bool big = full16 && h->tile_h == 16 && (h->conv_impl == 1 || h->conv_impl == 2);
+    // auto: staged bytes per MFMA fall 42 % with 16x16 tiles (measured +2-3 % on the deep layers), but the
+    // high-resolution layers and the 32-column kernel prefer three 8x16 workgroups per CU
+    if (h->conv_impl == 2 && h->tile_h == 0) big = full16 && L.NT == 2 && in.H <= 64 && in.W <= 64;
     const int th = big ? 16 : 8;
     ConvArgs a;
     a.in = in.p;
@@ -439,10 +461,23 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     a.prio_mode = h->prio_mode;
     a.ksplit = 1;
     a.partial = h->d_partial;
-    if (h->conv_impl == 1) {
+    int impl = h->conv_impl;
+    if (impl == 1 || impl == 2) {
         const int nt = (L.mode == 0) ? L.Cout_p / (32 * L.NT) : 4 * L.Cout_p / 64;
-        const int ms = ((L.NT == 2) ? 2 : 1) * (big ? 2 : 1);
-        a.ksplit = pick_ksplit(a.n_spatial * nt, a.n_chunks, h->n_cu * h->wg_per_cu, ms, h->splitk != 0 && h->d_partial != nullptr);
+        const int tiles8 = B * a.tiles_x * ((in.H + 7) / 8);
+        const int ks = pick_ksplit(tiles8 * nt, a.n_chunks, h->n_cu * h->wg_per_cu, (L.NT == 2) ? 2 : 1,
+                                   h->splitk != 0 && h->d_partial != nullptr);
+        // The occupancy variant needs at least one full round of workgroups (2/CU on 16x16 tiles, 3/CU on
+        // 8x16); below that the persistent kernel (2/CU, balanced static schedule, split-K when the launch
+        // cannot even fill a quarter of the chip) is faster.
+        const bool occ_fills = (a.n_spatial * nt >= h->n_cu * (big ? 2 : 3));
+        if (ks > 1 || (impl == 2 && !occ_fills)) {
+            impl = 1;
+            big = false;
+            a.tiles_y = (in.H + 7) / 8;
+            a.n_spatial = tiles8;
+            a.ksplit = ks;
+        }
     }
     a.stamps = nullptr;
     if (h->prof && h->d_stamps) {  // diagnostic clock stamps, profile runs only
@@ -454,9 +489,20 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         const int n_ntiles = L.Cout_p / (32 * L.NT);
         if (out.H != in.H || out.W != in.W) return fail(OG_EINVAL, "conv shape mismatch");
         const double fl = 2.0 * px * 9.0 * L.Cin * L.Cout;
-        if (h->conv_impl == 0) {
+        if (impl == 0) {
             prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma<2,0,8>" : "k_conv_mfma<1,0,8>", fl);
             rc = (L.NT == 2) ? launch_conv_t<2, 0, TH>(h, a, n_ntiles) : launch_conv_t<1, 0, TH>(h, a, n_ntiles);
+        } else if (impl == 2 && big) {
+            a.ksplit = 1;
+            prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma_o<2,0,16>" : "k_conv_mfma_o<1,0,16>", fl);
+            rc = (L.NT == 2) ? launch_conv_o<2, 0, 16, 2>(ctx, a, n_ntiles) : launch_conv_o<1, 0, 16, 3>(ctx, a, n_ntiles);
+        } else if (impl == 2 || impl == 3) {
+            a.ksplit = 1;
+            prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma_o<2,0,8>" : "k_conv_mfma_o<1,0,8>", fl);
+            if (impl == 2)
+                rc = (L.NT == 2) ? launch_conv_o<2, 0, TH, 3>(ctx, a, n_ntiles) : launch_conv_o<1, 0, TH, 3>(ctx, a, n_ntiles);
+            else
+                rc = (L.NT == 2) ? launch_conv_o<2, 0, TH, 4>(ctx, a, n_ntiles) : launch_conv_o<1, 0, TH, 4>(ctx, a, n_ntiles);
         } else if (big && L.NT == 2) {
             a.ksplit = 1;
             if (h->tps_nt2 == 3) {
@@ -500,9 +546,13 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     }
     if (out.H != 2 * in.H || out.W != 2 * in.W) return fail(OG_EINVAL, "convT shape mismatch");
     const double flt = 2.0 * px * 4.0 * L.Cin * L.Cout;
-    if (h->conv_impl == 0) {
+    if (impl == 0) {
         prof_begin(h, L.name, "k_conv_mfma<2,1,8>", flt);
         rc = launch_conv_t<2, 1, TH>(h, a, 4 * L.Cout_p / 64);
+    } else if (impl >= 2 && h->convt_occ) {
+        a.ksplit = 1;
+        prof_begin(h, L.name, "k_conv_mfma_o<2,1,8>", flt);
+        rc = launch_conv_o<2, 1, TH, 3>(ctx, a, 4 * L.Cout_p / 64);
     } else {
         prof_begin(h, L.name, "k_conv_mfma_p<2,1,8,1>", flt);
         rc = launch_conv_p<2, 1, TH, 1>(ctx, a, 4 * L.Cout_p / 64);
@@ -866,13 +916,14 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     if (!h || !name) return fail(OG_EINVAL, "null argument");
     const std::string n(name);
     int* slot = nullptr;
-    if (n == "conv_impl" && (value == 0 || value == 1)) slot = &h->conv_impl;
+    if (n == "conv_impl" && value >= 0 && value <= 3) slot = &h->conv_impl;
     else if (n == "tps_nt1" && (value == 1 || value == 3 || value == 9)) slot = &h->tps_nt1;
     else if (n == "tps_nt2" && (value == 1 || value == 3)) slot = &h->tps_nt2;
     else if (n == "wg_per_cu" && value >= 1 && value <= 2) slot = &h->wg_per_cu;
     else if (n == "prio_mode" && value >= 0 && value <= 2) slot = &h->prio_mode;
     else if (n == "splitk" && (value == 0 || value == 1)) slot = &h->splitk;
-    else if (n == "tile_h" && (value == 8 || value == 16)) slot = &h->tile_h;
+    else if (n == "tile_h" && (value == 0 || value == 8 || value == 16)) slot = &h->tile_h;
+    else if (n == "convt_occ" && (value == 0 || value == 1)) slot = &h->convt_occ;
     if (!slot) return fail(OG_EINVAL, "unknown option or bad value: " + n);
     if (*slot != value) {
         if (h->stream) HIPCHK(hipStreamSynchronize(h->stream));

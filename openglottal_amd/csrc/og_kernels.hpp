@@ -264,6 +264,189 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
     }
 }
 
+// Occupancy variant: ONE halo buffer (reloaded at each chunk boundary, the stall is covered by the
+// other workgroups) -> 39 KB of LDS, so 3-4 workgroups fit a CU instead of 2.  Same arithmetic and
+// accumulation order as k_conv_mfma.
+template <int NT, int MODE, int TH, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
+    constexpr int TW = 16;
+    constexpr int PAD = (MODE == 0) ? 1 : 0;
+    constexpr int HW_ = TW + 2 * PAD;
+    constexpr int HH_ = TH + 2 * PAD;
+    constexpr int HALO_PIX = HW_ * HH_;
+    constexpr int HALO_BYTES = HALO_PIX * 128;
+    constexpr int HALO_PIECES = HALO_PIX * 8;
+    constexpr int HALO_IT = (HALO_PIECES + 255) / 256;
+    constexpr int TAPS = (MODE == 0) ? 9 : 1;
+    constexpr int WROWS = 32 * NT;
+    constexpr int WBYTES = WROWS * 128;
+    constexpr int WM = 4 / NT;
+    constexpr int MS = (TH / 2) / WM;  // 32-row M sub-tiles (2 pixel rows x 16) per wave
+    static_assert(MS >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const halo0 = smem;
+    unsigned char* const wbuf0 = smem + HALO_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % NT;
+    const int wm = wave / NT;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+
+    // ---- tile decode (scalar) ----
+    const int n_tile = blockIdx.x / a.n_spatial;
+    int sp = blockIdx.x - n_tile * a.n_spatial;
+    const int tiles_per_frame = a.tiles_x * a.tiles_y;
+    const int b = sp / tiles_per_frame;
+    sp -= b * tiles_per_frame;
+    const int tyi = sp / a.tiles_x;
+    const int ty0 = tyi * TH;
+    const int tx0 = (sp - tyi * a.tiles_x) * TW;
+
+    const float* in_frame = a.in + (long long)b * a.in_frame_stride + a.in_ch_off;
+
+    // ---- per-thread halo source pointers (fixed across channel chunks) ----
+    const float* hsrc[HALO_IT];
+    int hstep[HALO_IT];
+#pragma unroll
+    for (int it = 0; it < HALO_IT; ++it) {
+        const int q = it * 256 + tid;
+        const int p = q >> 3;
+        const int logical = (q & 7) ^ ((p >> 1) & 7);
+        const int hy = p / HW_;
+        const int hx = p - hy * HW_;
+        const int gy = ty0 + hy - PAD, gx = tx0 + hx - PAD;
+        const bool inb = (q < HALO_PIECES) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        hsrc[it] = inb ? in_frame + ((long long)gy * a.W + gx) * a.in_pix_stride + logical * 4 : a.zero_page + logical * 4;
+        hstep[it] = inb ? 32 : 0;
+    }
+    const bool last_valid = ((HALO_IT - 1) * 256 + tid) < HALO_PIECES;
+
+    const unsigned lds0 = og_lds_addr(smem);
+    auto stage_halo = [&](int buf, int c) {
+        const unsigned base = lds0 + wave * 1024;
+        (void)buf;
+#pragma unroll
+        for (int it = 0; it < HALO_IT; ++it) {
+            if (it < HALO_IT - 1 || last_valid) glds16(hsrc[it] + c * hstep[it], base + it * 4096);
+        }
+    };
+    const float* wtile = a.wpk + (long long)n_tile * a.n_chunks * TAPS * (WROWS * 32);
+    auto stage_w = [&](int stage, int step) {
+        const float* blk = wtile + (long long)step * (WROWS * 32) + tid * 4;
+        const unsigned base = lds0 + HALO_BYTES + stage * WBYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) glds16(blk + i * 1024, base + i * 4096);
+    };
+
+    // ---- fragment addressing ----
+    // A rows: i -> 2x2-window-major pixel order, so that the 4 accumulator registers
+    // (reg&3) of one lane are exactly one pooling window (see epilogue).
+    const int px0 = 2 * (li >> 2) + (li & 1);
+    const int pyl = (li >> 1) & 1;
+    const int brow = wn * 32 + li;
+    const int boff = brow * 128 + ((lh ^ ((brow >> 1) & 7)) << 4);
+
+    f32x16 acc[MS];
+#pragma unroll
+    for (int m = 0; m < MS; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    const int total_steps = a.n_chunks * TAPS;
+
+    stage_halo(0, 0);
+    stage_w(0, 0);
+    og_wait_dma();
+    __syncthreads();
+
+    int step = 0;
+    for (int c = 0; c < a.n_chunks; ++c) {
+        const unsigned char* hb = halo0;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t, ++step) {
+            if (step + 1 < total_steps) stage_w((step + 1) & 1, step + 1);
+
+            const unsigned char* wb = wbuf0 + (step & 1) * WBYTES;
+            const int dy = (MODE == 0) ? t / 3 : 0;
+            const int dx = (MODE == 0) ? t % 3 : 0;
+            int aoff[MS];
+#pragma unroll
+            for (int m = 0; m < MS; ++m) {
+                const int py = 2 * (wm * MS + m) + pyl + dy;
+                const int p = py * HW_ + px0 + dx;
+                aoff[m] = p * 128 + ((lh ^ ((p >> 1) & 7)) << 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // slot = (2j + lh) ^ swz  ==  ((lh ^ swz) << 4) ^ (j << 5) in bytes
+                const f32x4 bv = *(const f32x4*)(wb + (boff ^ (j << 5)));
+#pragma unroll
+                for (int m = 0; m < MS; ++m) {
+                    const f32x4 av = *(const f32x4*)(hb + (aoff[m] ^ (j << 5)));
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[m], 0, 0, 0);
+                }
+            }
+            og_wait_dma();
+            __syncthreads();
+        }
+        if (c + 1 < a.n_chunks) {  // every read of the halo buffer completed before the barrier above
+            stage_halo(0, c + 1);
+            og_wait_dma();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: affine (+ReLU), store, optional fused 2x2 max-pool ----
+    const int ncol = n_tile * WROWS + wn * 32 + li;  // GEMM column of this lane
+    int co = ncol, qd = 0;
+    if (MODE == 1) {
+        qd = ncol / a.aff_mod;
+        co = ncol - qd * a.aff_mod;
+    }
+    const float sc = a.scale[co];
+    const float sh = a.shift[co];
+    const int OW = (MODE == 1) ? 2 * a.W : a.W;
+    float* out_frame = a.out + (long long)b * a.out_frame_stride + a.out_ch_off + co;
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+        const int ms = wm * MS + m;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int wdw = 2 * g + lh;  // 2x2 window index along x within the sub-tile
+            float vmax = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float v = fmaf(acc[m][4 * g + rr], sc, sh);
+                v = og_act(v, a.act);
+                const int y = ty0 + 2 * ms + (rr >> 1);
+                const int x = tx0 + 2 * wdw + (rr & 1);
+                if (y < a.H && x < a.W) {
+                    if (MODE == 0) {
+                        out_frame[((long long)y * OW + x) * a.out_pix_stride] = v;
+                    } else {
+                        out_frame[((long long)(2 * y + (qd >> 1)) * OW + (2 * x + (qd & 1))) * a.out_pix_stride] = v;
+                    }
+                }
+                vmax = (rr == 0) ? v : fmaxf(vmax, v);
+            }
+            if (MODE == 0 && a.pool != nullptr) {
+                const int y = ty0 + 2 * ms, x = tx0 + 2 * wdw;
+                if (y < a.H && x < a.W) {
+                    float* pf = a.pool + (long long)b * a.pool_frame_stride + a.pool_ch_off + co;
+                    pf[((long long)(y >> 1) * (a.W >> 1) + (x >> 1)) * a.pool_pix_stride] = vmax;
+                }
+            }
+        }
+    }
+}
+
 // Shared epilogue of k_conv_mfma_p / k_splitk_epilogue: per-channel affine, activation, optional
 // residual, NHWC store (scattered for the transposed conv), optional fused 2x2 max-pool.
 template <int NT, int MODE, int TH>

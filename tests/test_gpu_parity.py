@@ -212,15 +212,20 @@ def test_kernel_variants_bit_identical(full):
     m.set_option("conv_impl", 0)
     _, a0, l0 = m.segment(fr, want_mask=False, want_logits=True)
     try:
-        for impl, t1, t2, wg in [(1, 3, 1, 2), (1, 1, 1, 2), (1, 9, 3, 2), (1, 3, 3, 1)]:
+        for impl, t1, t2, wg in [(1, 3, 1, 2), (1, 1, 1, 2), (1, 9, 3, 2), (1, 3, 3, 1), (2, 3, 1, 2), (3, 3, 1, 2)]:
             m.set_option("conv_impl", impl)
             m.set_option("tps_nt1", t1)
             m.set_option("tps_nt2", t2)
             m.set_option("wg_per_cu", wg)
             _, a1, l1 = m.segment(fr, want_mask=False, want_logits=True)
             assert np.array_equal(l0, l1) and np.array_equal(a0, a1), (impl, t1, t2, wg)
+            for th in (8, 16, 0):
+                m.set_option("tile_h", th)
+                _, a1, l1 = m.segment(fr, want_mask=False, want_logits=True)
+                assert np.array_equal(l0, l1) and np.array_equal(a0, a1), (impl, t1, t2, wg, th)
     finally:
-        m.set_option("conv_impl", 1)
+        m.set_option("conv_impl", 2)
+        m.set_option("tile_h", 0)
         m.set_option("tps_nt1", 3)
         m.set_option("tps_nt2", 1)
         m.set_option("wg_per_cu", 2)

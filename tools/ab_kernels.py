@@ -12,11 +12,14 @@ m = og.UNet(1, 1, feats); m.load_state_dict(sd); m.to("cuda:0").eval(); m.set_ch
 F = 256
 frames = torch.from_numpy(synth.bulk_gray_frames(F)).cuda()
 area = torch.zeros(F, dtype=torch.int32, device="cuda")
-variants = {"gen1 (one tile per WG)": dict(conv_impl=0, tile_h=8, prio_mode=0),
+variants = {"gen1 (one tile per WG)": dict(conv_impl=0, tile_h=8, prio_mode=0, convt_occ=0),
             "gen2 th8": dict(conv_impl=1, tile_h=8, tps_nt1=3, tps_nt2=1, wg_per_cu=2, prio_mode=0),
             "gen2 th8 prio2 (default)": dict(conv_impl=1, tile_h=8, tps_nt1=3, tps_nt2=1, wg_per_cu=2, prio_mode=2),
             "gen2 th8 1wg/cu": dict(conv_impl=1, tile_h=8, tps_nt1=3, tps_nt2=1, wg_per_cu=1, prio_mode=0),
-            "gen2 th16 (1 wg/cu) t1=9,t2=3": dict(conv_impl=1, tile_h=16, tps_nt1=9, tps_nt2=3, wg_per_cu=2, prio_mode=0)}
+            "occ3 (single halo buf, 3 wg/cu)": dict(conv_impl=2, tile_h=8, prio_mode=0),
+            "occ3 + convT occ": dict(conv_impl=2, tile_h=8, prio_mode=0, convt_occ=1),
+            "occ th16 + convT occ": dict(conv_impl=2, tile_h=16, prio_mode=0, convt_occ=1),
+            "auto (default)": dict(conv_impl=2, tile_h=0, prio_mode=2, convt_occ=1)}
 res = {k: [] for k in variants}
 for rnd in range(5):
     for name, opts in variants.items():
@@ -29,7 +32,7 @@ for rnd in range(5):
         m.sync()
         res[name].append(2 * F / (time.perf_counter() - t0))
 for name, v in res.items():
-    print(f"{name:30s} median {np.median(v):8.1f} fps  max {max(v):8.1f}  min {min(v):8.1f}", flush=True)
+    print(f"{name:34s} median {np.median(v):8.1f} fps  max {max(v):8.1f}  min {min(v):8.1f}", flush=True)
 if len(sys.argv) > 2:
     for name in sys.argv[2:]:
         for k, v in variants[name].items():
