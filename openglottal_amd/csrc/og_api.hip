@@ -370,7 +370,7 @@ int launch_conv_p(const LaunchCtx& c, const ConvArgs& a, int n_ntiles) {
     hipLaunchKernelGGL((k_conv_mfma_p<NT, MODE, TH, TPS>), dim3(grid), dim3(256), lds, c.stream, a, n_items);
     HIPCHK(hipGetLastError());
     if (a.ksplit > 1) {
-        hipLaunchKernelGGL((k_splitk_epilogue<NT, MODE, TH>), dim3(a.n_spatial * n_ntiles), dim3(256), 0, c.stream, a);
+        hipLaunchKernelGGL((k_splitk_epilogue<NT, MODE, TH>), dim3(a.n_spatial * n_ntiles), dim3(256), 4 * 5120, c.stream, a);
         HIPCHK(hipGetLastError());
     }
     return OG_OK;
@@ -403,7 +403,7 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     if ((rc = set_conv_p_attr<1, 0, 8, 9>())) return rc;
     if ((rc = set_conv_p_attr<2, 1, 8, 1>())) return rc;
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 18 * 128 + 2 * 64 * 128));
-    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 16, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 18 * 128 + 2 * 32 * 128));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 18 * 128 + 2 * 32 * 128));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 1, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8 * 128 + 2 * 64 * 128));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 10 * 128 + 2 * 64 * 128));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 10 * 128 + 2 * 32 * 128));
@@ -495,7 +495,7 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         } else if (impl == 2 && big) {
             a.ksplit = 1;
             prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma_o<2,0,16>" : "k_conv_mfma_o<1,0,16>", fl);
-            rc = (L.NT == 2) ? launch_conv_o<2, 0, 16, 2>(ctx, a, n_ntiles) : launch_conv_o<1, 0, 16, 3>(ctx, a, n_ntiles);
+            rc = (L.NT == 2) ? launch_conv_o<2, 0, 16, 2>(ctx, a, n_ntiles) : launch_conv_o<1, 0, 16, 2>(ctx, a, n_ntiles);
         } else if (impl == 2 || impl == 3) {
             a.ksplit = 1;
             prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma_o<2,0,8>" : "k_conv_mfma_o<1,0,8>", fl);

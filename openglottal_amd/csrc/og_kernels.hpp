@@ -264,6 +264,79 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
     }
 }
 
+// Shared epilogue of k_conv_mfma_p / k_conv_mfma_o / k_splitk_epilogue: per-channel affine, activation,
+// optional residual, NHWC store (scattered for the transposed conv), optional fused 2x2 max-pool.
+//
+// The accumulator layout has one output channel per lane, so the natural store is 16 dword stores
+// (4 B/lane) per 32x32 tile.  Vector-memory instructions are what this kernel cannot afford (each costs
+// the SIMD ~85 cycles of matrix-pipe time, tools/ubench/mfma_f32_mix.hip), so the tile is transposed
+// through a private 4 KB LDS scratch (the staging buffers are dead by now) and leaves as 4 dwordx4
+// stores: 8 lanes write one pixel's 32 channels (128 B).  `scratch` = this wave's 5 KB (4 KB tile + 1 KB pooled tile).
+template <int NT, int MODE, int TH>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16* acc, int n_tile, int b, int ty0, int tx0, int wm, int wn,
+                                              int li, int lh, float sc, float sh, unsigned char* scratch) {
+    constexpr int WROWS = 32 * NT;
+    constexpr int WM = 4 / NT;
+    constexpr int MS = (TH / 2) / WM;
+    const int lane = li + 32 * lh;
+    const int ncol0 = n_tile * WROWS + wn * 32;   // first GEMM column of this wave's tile
+    int cbase = ncol0, qd = 0;                    // first output channel of the tile (+ quadrant for convT)
+    if (MODE == 1) {
+        qd = ncol0 / a.aff_mod;
+        cbase = ncol0 - qd * a.aff_mod;
+    }
+    const int co = cbase + li;
+    const int OW = (MODE == 1) ? 2 * a.W : a.W;
+    float* const fs = (float*)scratch;
+    const int rrow = lane >> 3;          // read-back: this lane handles pixel rows rrow + 8q, channels 4*(lane&7)..+3
+    const int rc4 = (lane & 7) * 4;
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+        const int ms = wm * MS + m;
+        float vmaxs[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int wdw = 2 * g + lh;
+            float vmax = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float v = fmaf(acc[m][4 * g + rr], sc, sh);
+                v = og_act(v, a.act);
+                if (MODE != 1 && a.res != nullptr) {
+                    const int y = ty0 + 2 * ms + (rr >> 1), x = tx0 + 2 * wdw + (rr & 1);
+                    if (y < a.H && x < a.W)
+                        v += a.res[(long long)b * a.res_frame_stride + ((long long)y * OW + x) * a.res_pix_stride + a.res_ch_off + co];
+                }
+                fs[(4 * wdw + rr) * 32 + li] = v;   // [pixel row i = 4*window + rr][channel]
+                vmax = (rr == 0) ? v : fmaxf(vmax, v);
+            }
+            vmaxs[g] = vmax;
+        }
+        // full-resolution tile: 4 x (64 lanes x 16 B)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = rrow + 8 * q;
+            const f32x4 v4 = *(const f32x4*)(fs + i * 32 + rc4);
+            const int wdw = i >> 2, rr = i & 3;
+            const int y = ty0 + 2 * ms + (rr >> 1), x = tx0 + 2 * wdw + (rr & 1);
+            if (y < a.H && x < a.W) {
+                const long long pix = (MODE != 1) ? ((long long)y * OW + x) : ((long long)(2 * y + (qd >> 1)) * OW + (2 * x + (qd & 1)));
+                *(f32x4*)(a.out + (long long)b * a.out_frame_stride + pix * a.out_pix_stride + a.out_ch_off + cbase + rc4) = v4;
+            }
+        }
+        if (MODE == 0 && a.pool != nullptr) {
+            // pooled tile: 8 windows x 32 channels = exactly one 16-B store per lane
+#pragma unroll
+            for (int g = 0; g < 4; ++g) fs[1024 + (2 * g + lh) * 32 + li] = vmaxs[g];   // scratch bytes [4096, 5120)
+            const f32x4 p4 = *(const f32x4*)(fs + 1024 + rrow * 32 + rc4);
+            const int y = ty0 + 2 * ms, x = tx0 + 2 * rrow;
+            if (y < a.H && x < a.W)
+                *(f32x4*)(a.pool + (long long)b * a.pool_frame_stride + ((long long)(y >> 1) * (a.W >> 1) + (x >> 1)) * a.pool_pix_stride +
+                          a.pool_ch_off + cbase + rc4) = p4;
+        }
+    }
+}
+
 // Occupancy variant: ONE halo buffer (reloaded at each chunk boundary, the stall is covered by the
 // other workgroups) -> 39 KB of LDS, so 3-4 workgroups fit a CU instead of 2.  Same arithmetic and
 // accumulation order as k_conv_mfma.
@@ -403,98 +476,11 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
         }
     }
 
-    // ---- epilogue: affine (+ReLU), store, optional fused 2x2 max-pool ----
-    const int ncol = n_tile * WROWS + wn * 32 + li;  // GEMM column of this lane
-    int co = ncol, qd = 0;
-    if (MODE == 1) {
-        qd = ncol / a.aff_mod;
-        co = ncol - qd * a.aff_mod;
-    }
-    const float sc = a.scale[co];
-    const float sh = a.shift[co];
-    const int OW = (MODE == 1) ? 2 * a.W : a.W;
-    float* out_frame = a.out + (long long)b * a.out_frame_stride + a.out_ch_off + co;
-#pragma unroll
-    for (int m = 0; m < MS; ++m) {
-        const int ms = wm * MS + m;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int wdw = 2 * g + lh;  // 2x2 window index along x within the sub-tile
-            float vmax = 0.f;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                float v = fmaf(acc[m][4 * g + rr], sc, sh);
-                v = og_act(v, a.act);
-                const int y = ty0 + 2 * ms + (rr >> 1);
-                const int x = tx0 + 2 * wdw + (rr & 1);
-                if (y < a.H && x < a.W) {
-                    if (MODE == 0) {
-                        out_frame[((long long)y * OW + x) * a.out_pix_stride] = v;
-                    } else {
-                        out_frame[((long long)(2 * y + (qd >> 1)) * OW + (2 * x + (qd & 1))) * a.out_pix_stride] = v;
-                    }
-                }
-                vmax = (rr == 0) ? v : fmaxf(vmax, v);
-            }
-            if (MODE == 0 && a.pool != nullptr) {
-                const int y = ty0 + 2 * ms, x = tx0 + 2 * wdw;
-                if (y < a.H && x < a.W) {
-                    float* pf = a.pool + (long long)b * a.pool_frame_stride + a.pool_ch_off + co;
-                    pf[((long long)(y >> 1) * (a.W >> 1) + (x >> 1)) * a.pool_pix_stride] = vmax;
-                }
-            }
-        }
-    }
-}
-
-// Shared epilogue of k_conv_mfma_p / k_splitk_epilogue: per-channel affine, activation, optional
-// residual, NHWC store (scattered for the transposed conv), optional fused 2x2 max-pool.
-template <int NT, int MODE, int TH>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16* acc, int n_tile, int b, int ty0, int tx0, int wm, int wn,
-                                              int li, int lh, float sc, float sh) {
-    constexpr int WROWS = 32 * NT;
-    constexpr int WM = 4 / NT;
-    constexpr int MS = (TH / 2) / WM;
-    const int ncol = n_tile * WROWS + wn * 32 + li;
-    int co = ncol, qd = 0;
-    if (MODE == 1) {
-        qd = ncol / a.aff_mod;
-        co = ncol - qd * a.aff_mod;
-    }
-    const int OW = (MODE == 1) ? 2 * a.W : a.W;
-    float* out_frame = a.out + (long long)b * a.out_frame_stride + a.out_ch_off + co;
-#pragma unroll
-    for (int m = 0; m < MS; ++m) {
-        const int ms = wm * MS + m;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int wdw = 2 * g + lh;
-            float vmax = 0.f;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                float v = fmaf(acc[m][4 * g + rr], sc, sh);
-                v = og_act(v, a.act);
-                const int y = ty0 + 2 * ms + (rr >> 1);
-                const int x = tx0 + 2 * wdw + (rr & 1);
-                if (y < a.H && x < a.W) {
-                    if (MODE != 1) {
-                        if (a.res != nullptr)
-                            v += a.res[(long long)b * a.res_frame_stride + ((long long)y * OW + x) * a.res_pix_stride + a.res_ch_off + co];
-                        out_frame[((long long)y * OW + x) * a.out_pix_stride] = v;
-                    } else {
-                        out_frame[((long long)(2 * y + (qd >> 1)) * OW + (2 * x + (qd & 1))) * a.out_pix_stride] = v;
-                    }
-                }
-                vmax = (rr == 0) ? v : fmaxf(vmax, v);
-            }
-            if (MODE == 0 && a.pool != nullptr) {
-                const int y = ty0 + 2 * ms, x = tx0 + 2 * wdw;
-                if (y < a.H && x < a.W) {
-                    float* pf = a.pool + (long long)b * a.pool_frame_stride + a.pool_ch_off + co;
-                    pf[((long long)(y >> 1) * (a.W >> 1) + (x >> 1)) * a.pool_pix_stride] = vmax;
-                }
-            }
-        }
+    // ---- epilogue (all staging buffers are dead behind the last barrier: LDS is scratch now) ----
+    {
+        const int ncol = n_tile * WROWS + wn * 32 + li;
+        const int co = (MODE == 1) ? ncol % a.aff_mod : ncol;
+        conv_epilogue<NT, MODE, TH>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, a.scale[co], a.shift[co], smem + wave * 5120);
     }
 }
 
@@ -780,7 +766,11 @@ __global__ __launch_bounds__(256, (TH >= 16) ? 1 : 2) void k_conv_mfma_p(ConvArg
                 sh = a.shift[co];
                 cached_ntile = n_tile;
             }
-            conv_epilogue<NT, MODE, TH>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, sc, sh);
+            // scratch: the halo buffer of the unit just finished (dead; the next unit's halo sits in the other one)
+            conv_epilogue<NT, MODE, TH>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, sc, sh, halo0 + ((u + 1) & 1) * HALO_BYTES + wave * ((MODE == 0) ? 5120 : 4096));  // no pooled tile without MODE 0: 4 x 4 KB fits the 16 KB halo
+            // the next item's first step DMAs the unit-after-next's halo into this very buffer: every wave must be
+            // done with its scratch first
+            __syncthreads();
         }
         item += G;
     }
@@ -824,7 +814,8 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(ConvArgs a) {
     }
     const int ncol = n_tile * WROWS + wn * 32 + li;
     const int co = (MODE == 1) ? ncol % a.aff_mod : ncol;
-    conv_epilogue<NT, MODE, TH>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, a.scale[co], a.shift[co]);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    conv_epilogue<NT, MODE, TH>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, a.scale[co], a.shift[co], smem + wave * 5120);
 }
 
 // First layer: Conv2d(1, f0, 3, pad 1) + BN + ReLU straight from the u8 frame
