@@ -106,10 +106,22 @@ struct og_unet {
     int tps_nt1 = 3;     // taps per step for the 32-column kernel
     int tps_nt2 = 1;     // taps per step for the 64-column kernel
     int prio_mode = 2;   // see ConvArgs::prio_mode (measured +1.2 % on the frame loop)
+    int fuse_head = 1;   // compute the 1x1 head + threshold + area inside the last conv's epilogue (Cout_p == 32 only)
+    int keep_taps = 0;   // fused head: still store the last activation tensor (og_unet_get_activation("ups.N.b"))
+    struct {
+        bool active = false;
+        float thr = 0.5f;
+        const int32_t* boxes = nullptr;
+        float* logits = nullptr;
+        uint8_t* mask = nullptr;
+        int32_t* area = nullptr;
+    } fuse;
     int convt_occ = 1;   // with conv_impl >= 2: run the transposed convs on the occupancy variant too
     int tile_h = 0;      // 0 auto (16x16 tiles for 64-channel-tile layers at <= 64x64 pixels, else 8x16) | 8 | 16
     int splitk = 1;      // allow split-K on launches that would fill < 1/4 of the chip (latency mode)
     float* d_partial = nullptr;
+    int32_t* d_counts = nullptr;  // fused head: per-(frame, tile, wave) foreground counts of the current chunk
+    size_t counts_cap = 0;
     int wg_per_cu = 2;   // persistent grid = wg_per_cu * CUs (capped by the item count)
     int n_cu = 256;
     std::map<GraphKey, hipGraphExec_t> graphs;
@@ -427,6 +439,7 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     // auto: staged bytes per MFMA fall 42 % with 16x16 tiles (measured +2-3 % on the deep layers), but the
     // high-resolution layers and the 32-column kernel prefer three 8x16 workgroups per CU
     if (h->conv_impl == 2 && h->tile_h == 0) big = full16 && L.NT == 2 && in.H <= 64 && in.W <= 64;
+    if (h->fuse.active) big = false;  // per-tile count slots are laid out for 8x16 tiles
     const int th = big ? 16 : 8;
     ConvArgs a;
     a.in = in.p;
@@ -459,6 +472,24 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     a.res_ch_off = 0;
     const LaunchCtx ctx{h->stream, h->n_cu, h->wg_per_cu};
     a.prio_mode = h->prio_mode;
+    a.head_w = nullptr;
+    a.head_bias = 0.f;
+    a.head_thr = 0.5f;
+    a.head_boxes = nullptr;
+    a.head_logits = nullptr;
+    a.head_mask = nullptr;
+    a.head_area = nullptr;
+    a.head_store_act = 0;
+    if (h->fuse.active) {  // set by enqueue_last_with_head for exactly one launch
+        a.head_w = h->d_head_w;
+        a.head_bias = h->head_bias;
+        a.head_thr = h->fuse.thr;
+        a.head_boxes = h->fuse.boxes;
+        a.head_logits = h->fuse.logits;
+        a.head_mask = h->fuse.mask;
+        a.head_area = h->fuse.area;
+        a.head_store_act = h->keep_taps;
+    }
     a.ksplit = 1;
     a.partial = h->d_partial;
     int impl = h->conv_impl;
@@ -471,12 +502,12 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         // 8x16); below that the persistent kernel (2/CU, balanced static schedule, split-K when the launch
         // cannot even fill a quarter of the chip) is faster.
         const bool occ_fills = (a.n_spatial * nt >= h->n_cu * (big ? 2 : 3));
-        if (ks > 1 || (impl == 2 && !occ_fills)) {
+        if ((ks > 1 && a.head_w == nullptr) || (impl == 2 && !occ_fills)) {
             impl = 1;
             big = false;
             a.tiles_y = (in.H + 7) / 8;
             a.n_spatial = tiles8;
-            a.ksplit = ks;
+            a.ksplit = (a.head_w == nullptr) ? ks : 1;  // the fused head lives in the conv epilogue: no split-K on that launch
         }
     }
     a.stamps = nullptr;
@@ -583,7 +614,11 @@ int enqueue_first(og_unet* h, int kind, const void* in, int B, int H, int W) {
     return OG_OK;
 }
 
-int enqueue_body(og_unet* h, int B) {
+bool can_fuse_head(const og_unet* h) {
+    return h->fuse_head && h->conv_impl != 0 && cp32(h->features[0]) == 32;
+}
+
+int enqueue_body(og_unet* h, int B, bool skip_last = false) {
     const int L = h->L;
     int rc;
     for (int i = 0; i < L; ++i) {
@@ -598,7 +633,39 @@ int enqueue_body(og_unet* h, int B) {
         const int Ci = cp32(h->features[i]);
         if ((rc = launch_conv(h, h->up_t[j], B, src, 0, h->CAT[i], Ci, nullptr))) return rc;
         if ((rc = launch_conv(h, h->dec_a[j], B, h->CAT[i], 0, h->UA[i], 0, nullptr))) return rc;
+        if (skip_last && j == L - 1) break;
         if ((rc = launch_conv(h, h->dec_b[j], B, h->UA[i], 0, h->UB[i], 0, nullptr))) return rc;
+    }
+    return OG_OK;
+}
+
+// Last conv (ups.N.net.3) with the head fused into its epilogue: replaces k_head and the 8 MB/frame round trip.
+int enqueue_last_with_head(og_unet* h, int B, float thr, const int32_t* boxes, uint8_t* mask, int32_t* area, float* logits) {
+    const int L = h->L;
+    const Act& u = h->UA[0];
+    const int tiles = ((u.W + 15) / 16) * ((u.H + 7) / 8);   // the fused launch always runs on 8x16 tiles (NT == 1)
+    const size_t need = (size_t)B * tiles * 4;
+    if (area && need > h->counts_cap) {
+        if (h->d_counts) {
+            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipFree(h->d_counts));
+            h->d_counts = nullptr;
+        }
+        HIPCHK(hipMalloc((void**)&h->d_counts, need * sizeof(int32_t)));
+        h->counts_cap = need;
+    }
+    h->fuse.active = true;
+    h->fuse.thr = thr;
+    h->fuse.boxes = boxes;
+    h->fuse.mask = mask;
+    h->fuse.area = area ? h->d_counts : nullptr;
+    h->fuse.logits = logits;
+    const int rc = launch_conv(h, h->dec_b[L - 1], B, u, 0, h->UB[0], 0, nullptr);
+    h->fuse.active = false;
+    if (rc) return rc;
+    if (area) {
+        hipLaunchKernelGGL(k_sum_counts, dim3(B), dim3(256), 0, h->stream, h->d_counts, tiles * 4, area);
+        HIPCHK(hipGetLastError());
     }
     return OG_OK;
 }
@@ -622,8 +689,9 @@ int run_chunk(og_unet* h, int kind, const void* in, int B, int H, int W, float t
     h->lastB = B;
     int rc;
     if ((rc = enqueue_first(h, kind, in, B, H, W))) return rc;
+    const bool fuse = can_fuse_head(h);
     if (!h->use_graphs) {
-        if ((rc = enqueue_body(h, B))) return rc;
+        if ((rc = enqueue_body(h, B, fuse))) return rc;
     } else {
         GraphKey key;
         memset(&key, 0, sizeof(key));
@@ -634,7 +702,7 @@ int run_chunk(og_unet* h, int kind, const void* in, int B, int H, int W, float t
         if (it == h->graphs.end()) {
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            rc = enqueue_body(h, B);
+            rc = enqueue_body(h, B, fuse);
             hipError_t e = hipStreamEndCapture(h->stream, &g);
             if (rc) {
                 if (g) (void)hipGraphDestroy(g);
@@ -649,6 +717,7 @@ int run_chunk(og_unet* h, int kind, const void* in, int B, int H, int W, float t
         }
         HIPCHK(hipGraphLaunch(it->second, h->stream));
     }
+    if (fuse) return enqueue_last_with_head(h, B, thr, boxes, mask, area, logits);
     return enqueue_head(h, B, H, W, thr, boxes, mask, area, logits);
 }
 
@@ -783,6 +852,7 @@ void og_unet_destroy(og_unet* h) {
     if (h->stage) (void)hipFree(h->stage);
     if (h->d_stamps) (void)hipFree(h->d_stamps);
     if (h->d_partial) (void)hipFree(h->d_partial);
+    if (h->d_counts) (void)hipFree(h->d_counts);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -924,6 +994,8 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "splitk" && (value == 0 || value == 1)) slot = &h->splitk;
     else if (n == "tile_h" && (value == 0 || value == 8 || value == 16)) slot = &h->tile_h;
     else if (n == "convt_occ" && (value == 0 || value == 1)) slot = &h->convt_occ;
+    else if (n == "fuse_head" && (value == 0 || value == 1)) slot = &h->fuse_head;
+    else if (n == "keep_taps" && (value == 0 || value == 1)) slot = &h->keep_taps;
     if (!slot) return fail(OG_EINVAL, "unknown option or bad value: " + n);
     if (*slot != value) {
         if (h->stream) HIPCHK(hipStreamSynchronize(h->stream));
@@ -1009,12 +1081,15 @@ int og_unet_forward_f32(og_unet* h, const float* x, int B, int H, int W, float* 
     HIPCHK(hipMemcpyAsync(s + o_in, x, B * HW * 4, hipMemcpyHostToDevice, h->stream));
     const int cb = h->chunk < B ? h->chunk : B;
     if ((rc = ensure_arena(h, cb > h->capB ? cb : h->capB, H, W))) return rc;
-    for (int b0 = 0; b0 < B; b0 += h->chunk) {
+    const int taps_saved = h->keep_taps;
+    h->keep_taps = 1;  // the parity/debug entry point keeps every layer-boundary tensor readable
+    for (int b0 = 0; b0 < B && !rc; b0 += h->chunk) {
         const int nb = (B - b0 < h->chunk) ? B - b0 : h->chunk;
         rc = run_chunk(h, KIND_F32, (const float*)(s + o_in) + b0 * HW, nb, H, W, 0.5f, nullptr, nullptr, nullptr,
                        (float*)(s + o_out) + b0 * HW);
-        if (rc) return rc;
     }
+    h->keep_taps = taps_saved;
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(logits, s + o_out, B * HW * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return OG_OK;
@@ -1108,8 +1183,11 @@ int og_unet_profile(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, in
         h->prof = &tr;
         HIPCHK(hipMemsetAsync(h->stage, 0, (size_t)B * 4, h->stream));
         rc = enqueue_first(h, KIND_U8, gray_dev, B, H, W);
-        if (!rc) rc = enqueue_body(h, B);
-        if (!rc) rc = enqueue_head(h, B, H, W, 0.5f, nullptr, nullptr, (int32_t*)h->stage, nullptr);
+        const bool fuse = can_fuse_head(h);
+        if (!rc) rc = enqueue_body(h, B, fuse);
+        if (!rc)
+            rc = fuse ? enqueue_last_with_head(h, B, 0.5f, nullptr, nullptr, (int32_t*)h->stage, nullptr)
+                      : enqueue_head(h, B, H, W, 0.5f, nullptr, nullptr, (int32_t*)h->stage, nullptr);
         h->prof = nullptr;
         hipError_t e = hipStreamSynchronize(h->stream);
         if (acc.empty()) acc.assign(tr.size(), 0.0);

@@ -78,6 +78,15 @@ struct ConvArgs {
     long long res_frame_stride;
     int res_pix_stride;
     int res_ch_off;
+    // Fused head (last U-Net conv only, Cout_p == 32): Conv2d(f0,1,1)+bias -> sigmoid -> > thr -> mask / area,
+    // i.e. k_head's arithmetic in the same order, applied to the tile while it sits in the LDS scratch.
+    const float* head_w;    // nullptr = no fusion
+    float head_bias, head_thr;
+    const int32_t* head_boxes;
+    float* head_logits;
+    uint8_t* head_mask;
+    int32_t* head_area;
+    int head_store_act;     // also store the activation tensor (parity/debug taps)
     int ksplit;             // >1: split-K.  Item = (tile, K-range); raw accumulators go to `partial`, and
     float* partial;         // k_splitk_epilogue sums them in split order and runs the epilogue (small-batch latency mode)
     int prio_mode;          // 0 off; 1/2: alternate s_setprio per unit, role = upper half of the grid / odd block
@@ -290,6 +299,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16* a
     float* const fs = (float*)scratch;
     const int rrow = lane >> 3;          // read-back: this lane handles pixel rows rrow + 8q, channels 4*(lane&7)..+3
     const int rc4 = (lane & 7) * 4;
+    int head_cnt = 0, hbx1 = 0, hby1 = 0, hbx2 = 1 << 30, hby2 = 1 << 30;
+    f32x4 wv = {0.f, 0.f, 0.f, 0.f};  // head weights of this lane's 4 channels: loaded ONCE, ahead of every store
+    if (MODE == 0 && NT == 1 && a.head_w != nullptr) wv = *(const f32x4*)(a.head_w + rc4);
+    if (MODE == 0 && NT == 1 && a.head_w != nullptr && a.head_boxes != nullptr) {
+        hbx1 = a.head_boxes[b * 4 + 0];
+        hby1 = a.head_boxes[b * 4 + 1];
+        hbx2 = a.head_boxes[b * 4 + 2];
+        hby2 = a.head_boxes[b * 4 + 3];
+        if (hbx1 < 0) { hbx1 = hby1 = hbx2 = hby2 = 0; }  // "no detection" -> area 0 (features.py:241-242)
+    }
 #pragma unroll
     for (int m = 0; m < MS; ++m) {
         const int ms = wm * MS + m;
@@ -313,15 +332,37 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16* a
             vmaxs[g] = vmax;
         }
         // full-resolution tile: 4 x (64 lanes x 16 B)
+        const bool fuse_head = (MODE == 0 && NT == 1 && a.head_w != nullptr);
+        const bool store_act = !fuse_head || a.head_store_act;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = rrow + 8 * q;
             const f32x4 v4 = *(const f32x4*)(fs + i * 32 + rc4);
             const int wdw = i >> 2, rr = i & 3;
             const int y = ty0 + 2 * ms + (rr >> 1), x = tx0 + 2 * wdw + (rr & 1);
-            if (y < a.H && x < a.W) {
+            const bool inb = (y < a.H && x < a.W);
+            if (inb && store_act) {
                 const long long pix = (MODE != 1) ? ((long long)y * OW + x) : ((long long)(2 * y + (qd >> 1)) * OW + (2 * x + (qd & 1)));
                 *(f32x4*)(a.out + (long long)b * a.out_frame_stride + pix * a.out_pix_stride + a.out_ch_off + cbase + rc4) = v4;
+            }
+            if (MODE == 0 && NT == 1 && fuse_head) {
+                float sdot = 0.f;
+                sdot = fmaf(v4.x, wv.x, sdot);
+                sdot = fmaf(v4.y, wv.y, sdot);
+                sdot = fmaf(v4.z, wv.z, sdot);
+                sdot = fmaf(v4.w, wv.w, sdot);
+                sdot += __shfl_xor(sdot, 1);
+                sdot += __shfl_xor(sdot, 2);
+                sdot += __shfl_xor(sdot, 4);
+                if ((lane & 7) == 0 && inb) {
+                    const float lg = sdot + a.head_bias;
+                    const float prob = 1.0f / (1.0f + expf(-lg));
+                    const bool on = prob > a.head_thr;
+                    const long long o = (long long)b * a.H * a.W + (long long)y * a.W + x;
+                    if (a.head_logits) a.head_logits[o] = lg;
+                    if (a.head_mask) a.head_mask[o] = on ? 255 : 0;
+                    head_cnt += (on && x >= hbx1 && x < hbx2 && y >= hby1 && y < hby2) ? 1 : 0;
+                }
             }
         }
         if (MODE == 0 && a.pool != nullptr) {
@@ -335,6 +376,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16* a
                           a.pool_ch_off + cbase + rc4) = p4;
         }
     }
+    if (MODE == 0 && NT == 1 && a.head_w != nullptr && a.head_area != nullptr) {
+        // one plain store per wave into a per-(frame, tile, wave) slot; k_sum_counts adds them up per frame.
+        // (131 072 atomics onto 64 addresses per launch were measured to double this kernel's time.)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) head_cnt += __shfl_down(head_cnt, o);
+        if (lane == 0) {
+            const int tile = (ty0 / TH) * a.tiles_x + (tx0 >> 4);
+            a.head_area[((long long)b * a.tiles_x * a.tiles_y + tile) * 4 + (wm * NT + wn)] = head_cnt;
+        }
+    }
+}
+
+// Per-frame sum of the fused head's per-(tile, wave) pixel counts -> area[b]  (features.py:238 / 244-245).
+__global__ __launch_bounds__(256) void k_sum_counts(const int32_t* __restrict__ counts, int per_frame, int32_t* __restrict__ area) {
+    __shared__ int s[256];
+    const int b = blockIdx.x;
+    int acc = 0;
+    for (int i = threadIdx.x; i < per_frame; i += 256) acc += counts[(long long)b * per_frame + i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) area[b] = s[0];
 }
 
 // Occupancy variant: ONE halo buffer (reloaded at each chunk boundary, the stall is covered by the

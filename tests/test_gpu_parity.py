@@ -226,6 +226,10 @@ def test_kernel_variants_bit_identical(full):
     finally:
         m.set_option("conv_impl", 2)
         m.set_option("tile_h", 0)
+        m.set_option("fuse_head", 0)   # fused vs separate head kernel: same arithmetic order -> identical bits
+        _, a2, l2 = m.segment(fr, want_mask=False, want_logits=True)
+        assert np.array_equal(l0, l2) and np.array_equal(a0, a2)
+        m.set_option("fuse_head", 1)
         m.set_option("tps_nt1", 3)
         m.set_option("tps_nt2", 1)
         m.set_option("wg_per_cu", 2)
