@@ -58,7 +58,7 @@ struct Act {  // NHWC activation view
 };
 
 struct GraphKey {
-    int B, H, W;
+    int B, H, W, flags;
     bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
 };
 
@@ -106,6 +106,7 @@ struct og_unet {
     int tps_nt1 = 3;     // taps per step for the 32-column kernel
     int tps_nt2 = 1;     // taps per step for the 64-column kernel
     int prio_mode = 2;   // see ConvArgs::prio_mode (measured +1.2 % on the frame loop)
+    int fuse_first = 1;  // compute the first layer inside downs.0's second conv (u8 path, full launches only)
     int fuse_head = 1;   // compute the 1x1 head + threshold + area inside the last conv's epilogue (Cout_p == 32 only)
     int keep_taps = 0;   // fused head: still store the last activation tensor (og_unet_get_activation("ups.N.b"))
     struct {
@@ -414,6 +415,8 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     if ((rc = set_conv_p_attr<1, 0, 8, 3>())) return rc;
     if ((rc = set_conv_p_attr<1, 0, 8, 9>())) return rc;
     if ((rc = set_conv_p_attr<2, 1, 8, 1>())) return rc;
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               18 * 10 * 128 + 2 * 32 * 128 + (12 * 20 + 352) * 4));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 18 * 128 + 2 * 64 * 128));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 18 * 128 + 2 * 32 * 128));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 1, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8 * 128 + 2 * 64 * 128));
@@ -472,6 +475,10 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     a.res_ch_off = 0;
     const LaunchCtx ctx{h->stream, h->n_cu, h->wg_per_cu};
     a.prio_mode = h->prio_mode;
+    a.first_u8 = nullptr;
+    a.first_w9 = nullptr;
+    a.first_scale = nullptr;
+    a.first_shift = nullptr;
     a.head_w = nullptr;
     a.head_bias = 0.f;
     a.head_thr = 0.5f;
@@ -614,15 +621,64 @@ int enqueue_first(og_unet* h, int kind, const void* in, int B, int H, int W) {
     return OG_OK;
 }
 
+// downs.0's second conv with the first layer computed inside it (u8 frames in, no intermediate tensor).
+// Only the occupancy variant has the in-kernel producer; needs f0 <= 32, a launch that fills the chip,
+// and nobody asking for the "downs.0.a" tap.
+bool can_fuse_first(const og_unet* h, int kind, int B, int H, int W) {
+    if (!h->fuse_first || kind != KIND_U8 || h->conv_impl != 2 || h->keep_taps || cp32(h->features[0]) != 32) return false;
+    const int items = B * ((W + 15) / 16) * ((H + 7) / 8);
+    return items >= 3 * h->n_cu;
+}
+
+int enqueue_first_fused(og_unet* h, const uint8_t* gray, int B, int H, int W) {
+    const ConvLayer& L = h->enc_b[0];
+    const Act& out = h->CAT[0];
+    const Act& pool = h->P[0];
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_chunks = 1;
+    a.H = H;
+    a.W = W;
+    a.tiles_x = (W + 15) / 16;
+    a.tiles_y = (H + 7) / 8;
+    a.n_spatial = B * a.tiles_x * a.tiles_y;
+    a.wpk = L.d_w;
+    a.scale = L.d_scale;
+    a.shift = L.d_shift;
+    a.aff_mod = L.Cout_p;
+    a.out = out.p;
+    a.out_frame_stride = out.frame_stride();
+    a.out_pix_stride = out.C;
+    a.out_ch_off = 0;
+    a.pool = pool.p;
+    a.pool_frame_stride = pool.frame_stride();
+    a.pool_pix_stride = pool.C;
+    a.zero_page = h->d_zero;
+    a.act = 1;
+    a.ksplit = 1;
+    a.first_u8 = gray;
+    a.first_w9 = h->d_first_w;
+    a.first_scale = h->d_first_scale;
+    a.first_shift = h->d_first_shift;
+    constexpr int lds = 18 * 10 * 128 + 2 * 32 * 128 + (12 * 20 + 352) * 4;
+    prof_begin(h, "downs.0 (first + second conv fused)", "k_conv_mfma_o<1,0,8,FIRST>",
+               2.0 * B * H * W * 9.0 * (1.0 * h->features[0] + (double)h->features[0] * h->features[0]));
+    hipLaunchKernelGGL((k_conv_mfma_o<1, 0, 8, 3, true>), dim3(a.n_spatial), dim3(256), lds, h->stream, a);
+    prof_end(h);
+    HIPCHK(hipGetLastError());
+    return OG_OK;
+}
+
 bool can_fuse_head(const og_unet* h) {
     return h->fuse_head && h->conv_impl != 0 && cp32(h->features[0]) == 32;
 }
 
-int enqueue_body(og_unet* h, int B, bool skip_last = false) {
+int enqueue_body(og_unet* h, int B, bool skip_last = false, bool skip_first = false) {
     const int L = h->L;
     int rc;
     for (int i = 0; i < L; ++i) {
         if (i > 0 && (rc = launch_conv(h, h->enc_a[i], B, h->P[i - 1], 0, h->A[i], 0, nullptr))) return rc;
+        if (i == 0 && skip_first) continue;  // downs.0 ran as one fused launch in front of the graph
         if ((rc = launch_conv(h, h->enc_b[i], B, h->A[i], 0, h->CAT[i], 0, &h->P[i]))) return rc;
     }
     if ((rc = launch_conv(h, h->bott_a, B, h->P[L - 1], 0, h->BA, 0, nullptr))) return rc;
@@ -688,21 +744,27 @@ int run_chunk(og_unet* h, int kind, const void* in, int B, int H, int W, float t
               int32_t* area, float* logits) {
     h->lastB = B;
     int rc;
-    if ((rc = enqueue_first(h, kind, in, B, H, W))) return rc;
+    const bool ff = can_fuse_first(h, kind, B, H, W);
     const bool fuse = can_fuse_head(h);
+    if (ff) {
+        if ((rc = enqueue_first_fused(h, (const uint8_t*)in, B, H, W))) return rc;
+    } else if ((rc = enqueue_first(h, kind, in, B, H, W))) {
+        return rc;
+    }
     if (!h->use_graphs) {
-        if ((rc = enqueue_body(h, B, fuse))) return rc;
+        if ((rc = enqueue_body(h, B, fuse, ff))) return rc;
     } else {
         GraphKey key;
         memset(&key, 0, sizeof(key));
         key.B = B;
         key.H = H;
         key.W = W;
+        key.flags = (fuse ? 1 : 0) | (ff ? 2 : 0);
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            rc = enqueue_body(h, B, fuse);
+            rc = enqueue_body(h, B, fuse, ff);
             hipError_t e = hipStreamEndCapture(h->stream, &g);
             if (rc) {
                 if (g) (void)hipGraphDestroy(g);
@@ -995,6 +1057,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "tile_h" && (value == 0 || value == 8 || value == 16)) slot = &h->tile_h;
     else if (n == "convt_occ" && (value == 0 || value == 1)) slot = &h->convt_occ;
     else if (n == "fuse_head" && (value == 0 || value == 1)) slot = &h->fuse_head;
+    else if (n == "fuse_first" && (value == 0 || value == 1)) slot = &h->fuse_first;
     else if (n == "keep_taps" && (value == 0 || value == 1)) slot = &h->keep_taps;
     if (!slot) return fail(OG_EINVAL, "unknown option or bad value: " + n);
     if (*slot != value) {
@@ -1182,9 +1245,10 @@ int og_unet_profile(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, in
         std::vector<og_unet::ProfEntry> tr;
         h->prof = &tr;
         HIPCHK(hipMemsetAsync(h->stage, 0, (size_t)B * 4, h->stream));
-        rc = enqueue_first(h, KIND_U8, gray_dev, B, H, W);
+        const bool ff = can_fuse_first(h, KIND_U8, B, H, W);
+        rc = ff ? enqueue_first_fused(h, gray_dev, B, H, W) : enqueue_first(h, KIND_U8, gray_dev, B, H, W);
         const bool fuse = can_fuse_head(h);
-        if (!rc) rc = enqueue_body(h, B, fuse);
+        if (!rc) rc = enqueue_body(h, B, fuse, ff);
         if (!rc)
             rc = fuse ? enqueue_last_with_head(h, B, 0.5f, nullptr, nullptr, (int32_t*)h->stage, nullptr)
                       : enqueue_head(h, B, H, W, 0.5f, nullptr, nullptr, (int32_t*)h->stage, nullptr);

@@ -78,6 +78,13 @@ struct ConvArgs {
     long long res_frame_stride;
     int res_pix_stride;
     int res_ch_off;
+    // Fused first layer (k_conv_mfma_o<..., FIRST=true> only): the 32-channel halo of downs.0's SECOND conv is
+    // computed in-kernel from the u8 frame (/255, Conv2d(1,32,3), BN, ReLU: k_conv_first's arithmetic in the same
+    // order) instead of being staged from HBM.
+    const uint8_t* first_u8;
+    const float* first_w9;      // [9][32]
+    const float* first_scale;   // [32]
+    const float* first_shift;   // [32]
     // Fused head (last U-Net conv only, Cout_p == 32): Conv2d(f0,1,1)+bias -> sigmoid -> > thr -> mask / area,
     // i.e. k_head's arithmetic in the same order, applied to the tile while it sits in the LDS scratch.
     const float* head_w;    // nullptr = no fusion
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(256) void k_sum_counts(const int32_t* __restrict__ 
 // Occupancy variant: ONE halo buffer (reloaded at each chunk boundary, the stall is covered by the
 // other workgroups) -> 39 KB of LDS, so 3-4 workgroups fit a CU instead of 2.  Same arithmetic and
 // accumulation order as k_conv_mfma.
-template <int NT, int MODE, int TH, int OCC>
+template <int NT, int MODE, int TH, int OCC, bool FIRST = false>
 __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     constexpr int TW = 16;
     constexpr int PAD = (MODE == 0) ? 1 : 0;
@@ -497,8 +504,53 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
 
     const int total_steps = a.n_chunks * TAPS;
 
-    stage_halo(0, 0);
-    stage_w(0, 0);
+    if (FIRST) {
+        // halo tile of the first layer's OUTPUT, computed here: 12x20 u8 patch -> /255 -> 3x3 conv -> BN -> ReLU,
+        // written in the same swizzled [pixel][8 x 16 B] image the LDS-DMA would have produced
+        float* patch = (float*)(smem + HALO_BYTES + 2 * WBYTES);  // [HH_+2][HW_+2]
+        float* fw = patch + (HH_ + 2) * (HW_ + 2);                // w9[9][32] | scale[32] | shift[32]
+        const uint8_t* fin = a.first_u8 + (long long)b * a.H * a.W;
+        for (int i = tid; i < (HH_ + 2) * (HW_ + 2); i += 256) {
+            const int hy = i / (HW_ + 2), hx = i - hy * (HW_ + 2);
+            const int gy = ty0 + hy - 2, gx = tx0 + hx - 2;
+            patch[i] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (float)fin[(long long)gy * a.W + gx] / 255.0f : 0.f;
+        }
+        for (int i = tid; i < 352; i += 256) fw[i] = (i < 288) ? a.first_w9[i] : (i < 320 ? a.first_scale[i - 288] : a.first_shift[i - 320]);
+        stage_w(0, 0);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < HALO_IT; ++it) {
+            const int q = it * 256 + tid;
+            if (q < HALO_PIECES) {
+                const int p = q >> 3;
+                const int c0 = ((q & 7) ^ ((p >> 1) & 7)) * 4;
+                const int hy = p / HW_, hx = p - hy * HW_;
+                const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};   // outside the image: the second conv's zero padding
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const float xv = patch[(hy + t / 3) * (HW_ + 2) + hx + t % 3];
+                        const f32x4 wv = *(const f32x4*)(fw + t * 32 + c0);
+                        sacc.x = fmaf(xv, wv.x, sacc.x);
+                        sacc.y = fmaf(xv, wv.y, sacc.y);
+                        sacc.z = fmaf(xv, wv.z, sacc.z);
+                        sacc.w = fmaf(xv, wv.w, sacc.w);
+                    }
+                    const f32x4 sc4 = *(const f32x4*)(fw + 288 + c0), sh4 = *(const f32x4*)(fw + 320 + c0);
+                    o.x = fmaxf(fmaf(sacc.x, sc4.x, sh4.x), 0.f);
+                    o.y = fmaxf(fmaf(sacc.y, sc4.y, sh4.y), 0.f);
+                    o.z = fmaxf(fmaf(sacc.z, sc4.z, sh4.z), 0.f);
+                    o.w = fmaxf(fmaf(sacc.w, sc4.w, sh4.w), 0.f);
+                }
+                *(f32x4*)(halo0 + q * 16) = o;
+            }
+        }
+    } else {
+        stage_halo(0, 0);
+        stage_w(0, 0);
+    }
     og_wait_dma();
     __syncthreads();
 

@@ -226,10 +226,17 @@ def test_kernel_variants_bit_identical(full):
     finally:
         m.set_option("conv_impl", 2)
         m.set_option("tile_h", 0)
-        m.set_option("fuse_head", 0)   # fused vs separate head kernel: same arithmetic order -> identical bits
-        _, a2, l2 = m.segment(fr, want_mask=False, want_logits=True)
-        assert np.array_equal(l0, l2) and np.array_equal(a0, a2)
-        m.set_option("fuse_head", 1)
+        big = np.concatenate([frames] * 4)[:25]   # 25 frames: enough tiles for the fused-first launch to be taken
+        m.set_option("conv_impl", 0)
+        _, ab0, lb0 = m.segment(big, want_mask=False, want_logits=True)
+        m.set_option("conv_impl", 2)
+        for fh, ff in [(0, 0), (1, 0), (0, 1), (1, 1)]:   # fused vs separate head / first layer: same arithmetic order
+            m.set_option("fuse_head", fh)
+            m.set_option("fuse_first", ff)
+            _, a2, l2 = m.segment(fr, want_mask=False, want_logits=True)
+            assert np.array_equal(l0, l2) and np.array_equal(a0, a2), (fh, ff)
+            _, ab2, lb2 = m.segment(big, want_mask=False, want_logits=True)
+            assert np.array_equal(lb0, lb2) and np.array_equal(ab0, ab2), (fh, ff)
         m.set_option("tps_nt1", 3)
         m.set_option("tps_nt2", 1)
         m.set_option("wg_per_cu", 2)
