@@ -94,9 +94,19 @@ def area_waveform(frames, detector, model, device=None, threshold: float = 0.5) 
     if detector is not None:
         detector.reset()
         boxes = np.empty((n, 4), np.int32)
-        for i, f in enumerate(frames):
-            b = detector.detect(f)
-            boxes[i] = normalize_box(b, f.shape[1], f.shape[0])
+        batch = getattr(detector.model, "detect_batch", None)
+        if batch is not None and len(shapes) == 1 and all(s % 32 == 0 for s in next(iter(shapes))) and frames[0].ndim == 3:
+            # native backend, frames already at network size: the YOLO network is per-frame independent, so run it
+            # batched on the device; only the O(1)/frame temporal state machine (detector.py:61-96) is sequential
+            best = batch(np.stack(frames), detector.conf)
+            H, W = frames[0].shape[:2]
+            for i in range(n):
+                b = detector.update(best[i:i + 1, :4], best[i:i + 1, 4], W, H) if best[i, 4] >= 0 else detector.update(None, None, W, H)
+                boxes[i] = normalize_box(b, W, H)
+        else:
+            for i, f in enumerate(frames):
+                b = detector.detect(f)
+                boxes[i] = normalize_box(b, f.shape[1], f.shape[0])
     if shapes == {(NET_SIZE, NET_SIZE)}:
         gray = np.stack([bgr_to_gray(f) for f in frames])
         _, area, _ = model.segment(gray, threshold=threshold, boxes=boxes, want_mask=False)
