@@ -97,6 +97,17 @@ int og_mask_area_dev(og_unet* h, const uint8_t* mask_dev, int B, int H, int W, c
 /* = cv2.cvtColor(frame, COLOR_BGR2GRAY) (features.py:235) for [B,H,W,3] u8 on the device. */
 int og_bgr2gray_dev(og_unet* h, const uint8_t* bgr_dev, int B, int H, int W, uint8_t* gray_dev);
 
+/* YOLO-Crop+UNet on the device (scripts/eval_girafe.py:127-159 `unet_on_crop`, utils.py:97-186): per frame,
+ * crop boxes[b] from gray[b], letterbox it NEAREST into a size x size tile (zeros around), segment, project
+ * the tile mask back NEAREST and paste it into a zero frame.  geom[b] = {pad_top, pad_left, content_h,
+ * content_w} as `letterbox_with_info` returns them (host computes them: Python round()).  Boxes must be
+ * inside the frame; x1 < 0 or an empty box gives an all-zero mask.  size must be a multiple of 2^n_levels. */
+int og_unet_segment_crops_u8(og_unet* h, const uint8_t* gray, int B, int H, int W, const int32_t* boxes, const int32_t* geom,
+                             int size, float threshold, uint8_t* out_masks);
+int og_unet_segment_crops_u8_dev(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, const int32_t* boxes_dev,
+                                 const int32_t* geom_dev, int size, float threshold, uint8_t* tiles_scratch_dev,
+                                 uint8_t* tile_masks_scratch_dev, uint8_t* out_masks_dev);
+
 int og_unet_sync(og_unet* h);
 void* og_unet_stream(og_unet* h);          /* hipStream_t the handle launches on */
 

@@ -42,6 +42,10 @@ PROTOTYPES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "og_unet_segment_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "og_unet_segment_crops_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_float, C.c_void_p]),
+    "og_unet_segment_crops_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "og_mask_area_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "og_bgr2gray_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "og_unet_sync": (C.c_int, [C.c_void_p]),

@@ -1179,6 +1179,46 @@ int og_bgr2gray_dev(og_unet* h, const uint8_t* bgr, int B, int H, int W, uint8_t
     return OG_OK;
 }
 
+int og_unet_segment_crops_u8_dev(og_unet* h, const uint8_t* gray, int B, int H, int W, const int32_t* boxes, const int32_t* geom,
+                                 int size, float thr, uint8_t* tiles_scratch, uint8_t* tile_masks_scratch, uint8_t* out_masks) {
+    int rc = check_shape(h, B, size, size);
+    if (rc) return rc;
+    if (B == 0) return OG_OK;
+    if (!gray || !boxes || !geom || !tiles_scratch || !tile_masks_scratch || !out_masks || H <= 0 || W <= 0)
+        return fail(OG_EINVAL, "null buffer / bad size");
+    hipLaunchKernelGGL(k_crop_letterbox, dim3((size * size + 255) / 256, B), dim3(256), 0, h->stream, gray, H, W, boxes, geom, size,
+                       tiles_scratch);
+    HIPCHK(hipGetLastError());
+    if ((rc = og_unet_segment_u8_dev(h, tiles_scratch, B, size, size, thr, nullptr, tile_masks_scratch, nullptr, nullptr))) return rc;
+    hipLaunchKernelGGL(k_unletterbox_paste, dim3((H * W + 255) / 256, B), dim3(256), 0, h->stream, tile_masks_scratch, size, boxes, geom,
+                       H, W, out_masks);
+    HIPCHK(hipGetLastError());
+    return OG_OK;
+}
+
+int og_unet_segment_crops_u8(og_unet* h, const uint8_t* gray, int B, int H, int W, const int32_t* boxes, const int32_t* geom, int size,
+                             float thr, uint8_t* out_masks) {
+    int rc = check_shape(h, B, size, size);
+    if (rc) return rc;
+    if (B == 0) return OG_OK;
+    if (!gray || !boxes || !geom || !out_masks || H <= 0 || W <= 0) return fail(OG_EINVAL, "null buffer / bad size");
+    const size_t HW = (size_t)H * W, SS = (size_t)size * size;
+    const size_t o_gray = 0, o_box = al256(B * HW), o_geo = o_box + al256((size_t)B * 16), o_til = o_geo + al256((size_t)B * 16),
+                 o_tm = o_til + al256(B * SS), o_out = o_tm + al256(B * SS), tot = o_out + al256(B * HW);
+    // a dedicated staging area: og_unet_segment_u8_dev does not touch h->stage, so it can be reused here
+    if ((rc = ensure_stage(h, tot))) return rc;
+    char* s = (char*)h->stage;
+    HIPCHK(hipMemcpyAsync(s + o_gray, gray, B * HW, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(s + o_box, boxes, (size_t)B * 16, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(s + o_geo, geom, (size_t)B * 16, hipMemcpyHostToDevice, h->stream));
+    rc = og_unet_segment_crops_u8_dev(h, (const uint8_t*)(s + o_gray), B, H, W, (const int32_t*)(s + o_box), (const int32_t*)(s + o_geo),
+                                      size, thr, (uint8_t*)(s + o_til), (uint8_t*)(s + o_tm), (uint8_t*)(s + o_out));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out_masks, s + o_out, B * HW, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return OG_OK;
+}
+
 int og_unet_get_activation(og_unet* h, const char* name, int B, float* out, size_t cap, int* dims) {
     if (!h || !h->finalized || !h->arena) return fail(OG_ESTATE, "no forward has run yet");
     if (!name || !out || !dims || B < 1 || B > h->lastB) return fail(OG_EINVAL, "bad argument (B must be <= last chunk size)");

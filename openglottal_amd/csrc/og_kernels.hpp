@@ -1337,3 +1337,51 @@ __global__ __launch_bounds__(256) void k_yolo_decode(YoloDecodeArgs a) {
         o[0] = bx[0]; o[1] = bx[1]; o[2] = bx[2]; o[3] = bx[3]; o[4] = best_c;
     }
 }
+
+// =======================================================================================
+// YOLO-Crop+UNet geometry on the device (scripts/eval_girafe.py:127-159, utils.py:97-186):
+// crop the box, letterbox it NEAREST into a size x size tile (zero padded), and the inverse
+// (unletterbox NEAREST + paste into a zero frame).  Index rule = OpenCV INTER_NEAREST as restated in
+// openglottal_amd/geometry.py: src = min(floor(dst * src_len / dst_len), src_len - 1), in float64.
+// geom[b] = {pad_top, pad_left, content_h, content_w} is computed on the host (Python's round()).
+// A box with x2 <= x1 or y2 <= y1 (or x1 < 0) yields an all-zero tile / frame.
+// =======================================================================================
+__device__ __forceinline__ int og_nearest(int d, int src_len, int dst_len) {
+    const int s = (int)floor((double)d * ((double)src_len / (double)dst_len));
+    return s < src_len - 1 ? s : src_len - 1;
+}
+
+__global__ __launch_bounds__(256) void k_crop_letterbox(const uint8_t* __restrict__ gray, int H, int W, const int32_t* __restrict__ boxes,
+                                                        const int32_t* __restrict__ geom, int size, uint8_t* __restrict__ tiles) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= size * size) return;
+    const int ty = t / size, tx = t - ty * size;
+    const int x1 = boxes[b * 4], y1 = boxes[b * 4 + 1], x2 = boxes[b * 4 + 2], y2 = boxes[b * 4 + 3];
+    const int top = geom[b * 4], left = geom[b * 4 + 1], ch = geom[b * 4 + 2], cw = geom[b * 4 + 3];
+    uint8_t v = 0;
+    const int cy = ty - top, cx = tx - left;
+    if (x1 >= 0 && x2 > x1 && y2 > y1 && cy >= 0 && cy < ch && cx >= 0 && cx < cw) {
+        const int sy = og_nearest(cy, y2 - y1, ch), sx = og_nearest(cx, x2 - x1, cw);
+        v = gray[((long long)b * H + y1 + sy) * W + x1 + sx];
+    }
+    tiles[(long long)b * size * size + t] = v;
+}
+
+__global__ __launch_bounds__(256) void k_unletterbox_paste(const uint8_t* __restrict__ tiles, int size, const int32_t* __restrict__ boxes,
+                                                           const int32_t* __restrict__ geom, int H, int W, uint8_t* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    const int y = p / W, x = p - y * W;
+    const int x1 = boxes[b * 4], y1 = boxes[b * 4 + 1], x2 = boxes[b * 4 + 2], y2 = boxes[b * 4 + 3];
+    const int top = geom[b * 4], left = geom[b * 4 + 1], ch = geom[b * 4 + 2], cw = geom[b * 4 + 3];
+    uint8_t v = 0;
+    if (x1 >= 0 && x >= x1 && x < x2 && y >= y1 && y < y2) {
+        const int hh = y2 - y1, ww = x2 - x1;
+        const int sy = (ch == hh) ? (y - y1) : og_nearest(y - y1, ch, hh);
+        const int sx = (cw == ww) ? (x - x1) : og_nearest(x - x1, cw, ww);
+        v = tiles[(long long)b * size * size + (long long)(top + sy) * size + left + sx];
+    }
+    out[(long long)b * H * W + p] = v;
+}

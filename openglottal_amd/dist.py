@@ -66,3 +66,67 @@ def sharded_area_waveform(frames_gray: np.ndarray, model, rank: int, world: int,
     if device is not None:
         t = t.to(device)
     return all_gather_areas(t, n, group).cpu().numpy()
+
+
+def all_gather_rows(local, n_frames: int, width: int, group=None, force: bool = False):
+    """All-gather ragged per-rank ``[n_local, width]`` float32 rows (e.g. best boxes x1,y1,x2,y2,conf) into
+    ``[n_frames, width]``; slices are padded to ceil(n/world) rows so one fixed-size collective suffices."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.as_tensor(local, dtype=torch.float32).reshape(-1, width)
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
+        return t[:n_frames]
+    world = dist.get_world_size(group)
+    per = -(-n_frames // world)
+    pad = torch.full((per, width), -1.0, dtype=torch.float32, device=t.device)
+    pad[: t.shape[0]] = t
+    out = torch.empty(world * per, width, dtype=torch.float32, device=t.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(n_frames, r, world)
+        parts.append(out[r * per: r * per + (hi - lo)])
+    return torch.cat(parts)
+
+
+def sharded_gated_area_waveform(frames_bgr, detect_batch, make_detector, model, rank: int, world: int, device=None, group=None,
+                                conf: float = 0.25):
+    """Detection-gated area waveform (features.py:234-245 with a detector) with frames sharded over ranks.
+
+    SURVEY §8e: (1) every rank runs the per-frame-independent YOLO network on ITS frames and the per-frame
+    best boxes (5 floats) are all-gathered; (2) every rank replays the O(N) sequential TemporalDetector state
+    machine over the whole video (deterministic, so all ranks agree); (3) every rank segments its own frames
+    with its slice of the boxes; (4) the areas are all-gathered.
+
+    ``detect_batch(frames [n,H,W,3], conf) -> best [n,5]`` (conf = -1: no detection);
+    ``make_detector()`` returns a fresh ``TemporalDetector`` (only its ``update`` is used).
+    """
+    import torch
+
+    from .utils import bgr_to_gray, normalize_box
+
+    n = len(frames_bgr)
+    lo, hi = shard_range(n, rank, world)
+    H, W = frames_bgr[0].shape[:2]
+    mine = np.stack(frames_bgr[lo:hi]) if hi > lo else np.zeros((0, H, W, 3), np.uint8)
+    best_local = detect_batch(mine, conf) if hi > lo else np.zeros((0, 5), np.float32)
+    t = torch.from_numpy(np.ascontiguousarray(best_local, dtype=np.float32))
+    if device is not None:
+        t = t.to(device)
+    best = all_gather_rows(t, n, 5, group).cpu().numpy()
+    det = make_detector()
+    det.reset()
+    boxes = np.empty((n, 4), np.int32)
+    for i in range(n):
+        b = det.update(best[i:i + 1, :4], best[i:i + 1, 4], W, H) if best[i, 4] >= 0 else det.update(None, None, W, H)
+        boxes[i] = normalize_box(b, W, H)
+    if hi > lo:
+        gray = np.stack([bgr_to_gray(f) for f in mine])
+        _, area, _ = model.segment(gray, boxes=boxes[lo:hi], want_mask=False)
+    else:
+        area = np.zeros(0, np.int32)
+    ta = torch.from_numpy(np.ascontiguousarray(area))
+    if device is not None:
+        ta = ta.to(device)
+    return all_gather_areas(ta, n, group).cpu().numpy(), boxes

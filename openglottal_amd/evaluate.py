@@ -33,6 +33,9 @@ def unet_on_crops(grays: np.ndarray, boxes, model, device=None, crop_size: int =
     segmented in one call; masks are projected back NEAREST and pasted into zero frames."""
     if device is not None and getattr(model, "_device", None) is None:
         model.to(device)
+    if hasattr(model, "segment_crops") and crop_size % 16 == 0 and grays.ndim == 3 and all(
+            b is None or (0 <= b[0] and 0 <= b[1]) for b in boxes):
+        return model.segment_crops(grays, boxes, crop_size)   # whole geometry on the device
     out = np.zeros_like(grays)
     jobs, tiles = [], []
     for i, (g, b) in enumerate(zip(grays, boxes)):

@@ -44,8 +44,8 @@ def load_frames_bgr(source) -> list[np.ndarray]:
     """Frames of a video as BGR u8 arrays (utils.py:43-54).
 
     ``source`` may be an in-memory array/list of frames, a ``.npy``/``.npz`` file
-    (``[N,H,W,3]`` BGR or ``[N,H,W]`` gray), or a video file when OpenCV is
-    importable (AVI/MJPG decode is host I/O and stays on cv2).
+    (``[N,H,W,3]`` BGR or ``[N,H,W]`` gray), a directory of PNG/JPEG frames (Pillow), or a
+    video file when OpenCV is importable (AVI/MJPG decode is host I/O and stays on cv2).
     """
     if isinstance(source, np.ndarray):
         return list(source)
@@ -59,6 +59,15 @@ def load_frames_bgr(source) -> list[np.ndarray]:
         return list(z[z.files[0]])
     if not os.path.exists(p):
         return []
+    if os.path.isdir(p):  # image-sequence directory (GIRAFE ships frames as PNGs): decode with Pillow, no OpenCV needed
+        from PIL import Image
+
+        frames = []
+        for name in sorted(os.listdir(p)):
+            if name.lower().endswith((".png", ".jpg", ".jpeg", ".bmp")):
+                im = np.asarray(Image.open(os.path.join(p, name)))
+                frames.append(np.ascontiguousarray(im[..., 2::-1]) if im.ndim == 3 else im)  # RGB(A) -> BGR, gray stays 2-D
+        return frames
     try:
         import cv2  # noqa: F401
     except ImportError as e:

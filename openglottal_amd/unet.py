@@ -138,6 +138,33 @@ class UNet:
         check(lib().og_unet_segment_u8_dev(self._h, ptr(gray_dev), B, H, W, float(threshold), ptr(boxes_dev),
                                            ptr(mask_dev), ptr(area_dev), ptr(logits_dev)), "og_unet_segment_u8_dev")
 
+    def segment_crops(self, gray, boxes, crop_size: int = 256, threshold: float = 0.5):
+        """YOLO-Crop+UNet for ``[B,H,W]`` frames on the device: crop → letterbox (NEAREST) → U-Net → project back →
+        paste (`scripts/eval_girafe.py:127-159`).  ``boxes``: per frame ``(x1,y1,x2,y2)`` inside the frame, or
+        ``None``.  Returns full-frame masks ``[B,H,W]`` u8 {0,255}."""
+        self._require()
+        g = np.ascontiguousarray(gray, dtype=np.uint8)
+        B, H, W = g.shape
+        bx = np.full((B, 4), -1, np.int32)
+        geo = np.zeros((B, 4), np.int32)
+        for i, b in enumerate(boxes):
+            if b is None:
+                continue
+            x1, y1, x2, y2 = (int(v) for v in b)
+            x1, x2 = max(0, min(W, x1)), max(0, min(W, x2))   # python slice clamping for in-frame boxes
+            y1, y2 = max(0, min(H, y1)), max(0, min(H, y2))
+            h, w = y2 - y1, x2 - x1
+            if h <= 0 or w <= 0:
+                continue
+            scale = crop_size / max(h, w)
+            nh, nw = int(round(h * scale)), int(round(w * scale))
+            bx[i] = (x1, y1, x2, y2)
+            geo[i] = ((crop_size - nh) // 2, (crop_size - nw) // 2, nh, nw)
+        out = np.empty((B, H, W), np.uint8)
+        check(lib().og_unet_segment_crops_u8(self._h, ptr(g), B, H, W, ptr(bx), ptr(geo), int(crop_size), float(threshold), ptr(out)),
+              "og_unet_segment_crops_u8")
+        return out
+
     def sync(self) -> None:
         self._require()
         check(lib().og_unet_sync(self._h), "og_unet_sync")

@@ -395,3 +395,29 @@ def test_large_frames_and_large_ragged_batch(trained):
     idx = np.arange(203) % 80
     _, areas, _ = m.segment(frames[idx], want_mask=False)
     assert np.array_equal(areas.astype(np.int64), g["areas"][idx])
+
+
+def test_device_crop_letterbox_paste_equals_host_geometry(trained):
+    """Device YOLO-Crop+UNet (crop -> NEAREST letterbox -> U-Net -> NEAREST back-projection -> paste) must equal the
+    host-geometry pipeline pixel for pixel (same index rule, float64 floor)."""
+    from openglottal_amd import evaluate as E
+    from openglottal_amd.geometry import INTER_NEAREST, letterbox_with_info, unletterbox
+    g, sd, m, frames, gt = trained
+    rs = np.random.RandomState(4)
+    boxes = [(88, 40, 168, 216), None, (0, 0, 256, 256), (10, 10, 10, 50), (3, 7, 250, 31), (200, 100, 256, 256), (17, 19, 18, 20)]
+    for _ in range(9):
+        x1, y1 = rs.randint(0, 200, 2)
+        boxes.append((int(x1), int(y1), int(x1 + rs.randint(1, 256 - x1)), int(y1 + rs.randint(1, 256 - y1))))
+    fr = frames[:len(boxes)]
+    dev = m.segment_crops(fr, boxes)
+    assert dev.shape == fr.shape and set(np.unique(dev)) <= {0, 255}
+    for i, b in enumerate(boxes):   # host reference built from geometry.py + the plain segment call
+        want = np.zeros_like(fr[i])
+        if b is not None and b[2] > b[0] and b[3] > b[1]:
+            x1, y1, x2, y2 = b
+            crop = fr[i][y1:y2, x1:x2]
+            boxed, pt, pl, ch, cw = letterbox_with_info(crop, 256, value=0)
+            mk, _, _ = m.segment(boxed[None])
+            want[y1:y2, x1:x2] = unletterbox(mk[0], pt, pl, ch, cw, crop.shape[0], crop.shape[1], interp=INTER_NEAREST)
+        assert np.array_equal(dev[i], want), (i, b)
+    assert np.array_equal(E.unet_on_crops(fr, boxes, m), dev)

@@ -111,3 +111,21 @@ def test_normalize_box_python_slice_semantics():
         a, b, c, d = normalize_box(box, 40, 30)
         assert int(m[b:d, a:c].sum()) == want, box
     assert normalize_box(None, 40, 30) == (-1, -1, -1, -1)
+
+
+def test_load_frames_from_npy_and_png_directory(tmp_path):
+    from PIL import Image
+    from openglottal_amd.features import load_frames_bgr
+    rs = np.random.RandomState(2)
+    vid = rs.randint(0, 256, (3, 16, 24, 3), dtype=np.uint8)
+    np.save(tmp_path / "v.npy", vid)
+    got = load_frames_bgr(str(tmp_path / "v.npy"))
+    assert len(got) == 3 and np.array_equal(got[1], vid[1])
+    d = tmp_path / "seq"
+    d.mkdir()
+    for i in range(3):
+        Image.fromarray(vid[i][..., ::-1].copy()).save(d / f"f_{i:03d}.png")   # files hold RGB
+    Image.fromarray(vid[0][..., 0]).save(d / "g_999.png")                        # a grayscale frame
+    seq = load_frames_bgr(str(d))
+    assert len(seq) == 4 and all(np.array_equal(seq[i], vid[i]) for i in range(3)) and seq[3].ndim == 2
+    assert load_frames_bgr(str(tmp_path / "missing.avi")) == []
