@@ -27,8 +27,8 @@ area = torch.zeros(F, dtype=torch.int32, device="cuda")
 
 def run():
     td = og.TemporalDetector(lambda f, c: None)
-    for b0 in range(0, F, 64):
-        nb = min(64, F - b0)
+    for b0 in range(0, F, 256):
+        nb = min(256, F - b0)
         check(lib().og_yolo_detect_u8_dev(y._h, ptr(bgr[b0:]), nb, 256, 256, 0.25, ptr(best[b0:]), None), "yolo")
     check(lib().og_bgr2gray_dev(m._h, ptr(bgr), F, 256, 256, ptr(gray)), "gray")
     check(lib().og_yolo_sync(y._h), "sync")
@@ -49,8 +49,8 @@ for _ in range(n):
 el = time.perf_counter() - t0
 t1 = time.perf_counter()
 for _ in range(n):
-    for b0 in range(0, F, 64):
-        check(lib().og_yolo_detect_u8_dev(y._h, ptr(bgr[b0:]), min(64, F - b0), 256, 256, 0.25, ptr(best[b0:]), None), "yolo")
+    for b0 in range(0, F, 256):
+        check(lib().og_yolo_detect_u8_dev(y._h, ptr(bgr[b0:]), min(256, F - b0), 256, 256, 0.25, ptr(best[b0:]), None), "yolo")
     check(lib().og_yolo_sync(y._h), "sync")
 ely = time.perf_counter() - t1
 print(json.dumps({"pipeline": "YOLO+UNet (gated), 256x256, 1xMI355X", "frames": F, "fps": round(n * F / el, 1),
