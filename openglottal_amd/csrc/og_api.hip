@@ -106,6 +106,12 @@ struct og_unet {
     int tps_nt1 = 3;     // taps per step for the 32-column kernel
     int tps_nt2 = 1;     // taps per step for the 64-column kernel
     int prio_mode = 2;   // see ConvArgs::prio_mode (measured +1.2 % on the frame loop)
+    // Two lanes: odd micro-batches of one call run on a twin handle (own stream, arena, graphs; SHARED weights), so
+    // the launch tails of one chain are filled by the other chain's kernels (+2-4 % measured, tools/two_streams.py).
+    og_unet* twin = nullptr;
+    bool is_twin = false;
+    int dual = 1;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int fuse_first = 1;  // compute the first layer inside downs.0's second conv (u8 path, full launches only)
     int fuse_head = 1;   // compute the 1x1 head + threshold + area inside the last conv's epilogue (Cout_p == 32 only)
     int keep_taps = 0;   // fused head: still store the last activation tensor (og_unet_get_activation("ups.N.b"))
@@ -902,14 +908,22 @@ og_unet* og_unet_create(const int* features, int n_levels, int in_ch, int out_ch
 
 void og_unet_destroy(og_unet* h) {
     if (!h) return;
+    if (h->twin) {
+        og_unet_destroy(h->twin);
+        h->twin = nullptr;
+    }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
-    for (auto* v : {&h->enc_a, &h->enc_b, &h->up_t, &h->dec_a, &h->dec_b})
-        for (auto& l : *v) free_layer(l);
-    free_layer(h->bott_a);
-    free_layer(h->bott_b);
-    for (float* p : {h->d_first_w, h->d_first_scale, h->d_first_shift, h->d_head_w, h->d_zero})
-        if (p) (void)hipFree(p);
+    if (!h->is_twin) {  // a twin borrows every weight pointer from its owner
+        for (auto* v : {&h->enc_a, &h->enc_b, &h->up_t, &h->dec_a, &h->dec_b})
+            for (auto& l : *v) free_layer(l);
+        free_layer(h->bott_a);
+        free_layer(h->bott_b);
+        for (float* p : {h->d_first_w, h->d_first_scale, h->d_first_shift, h->d_head_w, h->d_zero})
+            if (p) (void)hipFree(p);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->arena) (void)hipFree(h->arena);
     if (h->stage) (void)hipFree(h->stage);
     if (h->d_stamps) (void)hipFree(h->d_stamps);
@@ -1027,20 +1041,48 @@ int og_unet_finalize(og_unet* h) {
     }
     h->host.clear();
     h->finalized = true;
+    {   // twin lane: same weights (pointers shared), own stream / events / split-K workspace; arena on demand
+        og_unet* t = new og_unet();
+        t->is_twin = true;
+        t->features = h->features;
+        t->L = h->L;
+        t->finalized = true;
+        t->d_first_w = h->d_first_w;
+        t->d_first_scale = h->d_first_scale;
+        t->d_first_shift = h->d_first_shift;
+        t->enc_a = h->enc_a;
+        t->enc_b = h->enc_b;
+        t->bott_a = h->bott_a;
+        t->bott_b = h->bott_b;
+        t->up_t = h->up_t;
+        t->dec_a = h->dec_a;
+        t->dec_b = h->dec_b;
+        t->d_head_w = h->d_head_w;
+        t->head_bias = h->head_bias;
+        t->d_zero = h->d_zero;
+        t->n_cu = h->n_cu;
+        h->twin = t;
+        HIPCHK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&t->ev0));
+        HIPCHK(hipEventCreate(&t->ev1));
+        HIPCHK(hipMalloc((void**)&t->d_partial, kPartialBytes));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
     return OG_OK;
 }
 
 int og_unet_set_chunk(og_unet* h, int n) {
     if (!h || n < 1 || n > 4096) return fail(OG_EINVAL, "chunk must be in 1..4096");
-    if (n != h->chunk) {
-        h->chunk = n;
-    }
+    h->chunk = n;
+    if (h->twin) h->twin->chunk = n;
     return OG_OK;
 }
 
 int og_unet_set_graphs(og_unet* h, int enable) {
     if (!h) return fail(OG_EINVAL, "null handle");
     h->use_graphs = enable ? 1 : 0;
+    if (h->twin) h->twin->use_graphs = h->use_graphs;
     return OG_OK;
 }
 
@@ -1059,12 +1101,14 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "fuse_head" && (value == 0 || value == 1)) slot = &h->fuse_head;
     else if (n == "fuse_first" && (value == 0 || value == 1)) slot = &h->fuse_first;
     else if (n == "keep_taps" && (value == 0 || value == 1)) slot = &h->keep_taps;
+    else if (n == "dual" && (value == 0 || value == 1)) slot = &h->dual;
     if (!slot) return fail(OG_EINVAL, "unknown option or bad value: " + n);
     if (*slot != value) {
         if (h->stream) HIPCHK(hipStreamSynchronize(h->stream));
         drop_graphs(h);
         *slot = value;
     }
+    if (h->twin) return og_unet_set_option(h->twin, name, value);
     return OG_OK;
 }
 
@@ -1099,11 +1143,24 @@ int og_unet_segment_u8_dev(og_unet* h, const uint8_t* gray, int B, int H, int W,
     if ((rc = ensure_arena(h, cb > h->capB ? cb : h->capB, H, W))) return rc;
     if (area) HIPCHK(hipMemsetAsync(area, 0, (size_t)B * sizeof(int32_t), h->stream));
     const size_t HW = (size_t)H * W;
-    for (int b0 = 0; b0 < B; b0 += h->chunk) {
+    const int n_chunks = (B + h->chunk - 1) / h->chunk;
+    og_unet* t = (h->dual && h->twin && n_chunks >= 2) ? h->twin : nullptr;
+    if (t) {  // the twin's chain must see everything enqueued so far on this stream (area memset, caller's H2D copies)
+        if ((rc = ensure_arena(t, cb > t->capB ? cb : t->capB, H, W))) return rc;
+        HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+        HIPCHK(hipStreamWaitEvent(t->stream, h->ev_fork, 0));
+    }
+    int k = 0;
+    for (int b0 = 0; b0 < B; b0 += h->chunk, ++k) {
         const int nb = (B - b0 < h->chunk) ? B - b0 : h->chunk;
-        rc = run_chunk(h, KIND_U8, gray + b0 * HW, nb, H, W, thr, boxes ? boxes + 4 * b0 : nullptr,
+        og_unet* lane = (t && (k & 1)) ? t : h;
+        rc = run_chunk(lane, KIND_U8, gray + b0 * HW, nb, H, W, thr, boxes ? boxes + 4 * b0 : nullptr,
                        mask ? mask + b0 * HW : nullptr, area ? area + b0 : nullptr, logits ? logits + b0 * HW : nullptr);
         if (rc) return rc;
+    }
+    if (t) {  // join: whatever follows on this stream (D2H copies, og_unet_sync) also waits for the twin's chain
+        HIPCHK(hipEventRecord(h->ev_join, t->stream));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     }
     return OG_OK;
 }
