@@ -22,6 +22,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = f32 vector peak
+PEAK_HBM_BYTES = 8.0e12
+LAYER_BOUNDARY_BYTES_PER_FRAME = 183.5e6  # every layer reads its inputs once and writes its output once, fp32
 DOMINANT = "k_conv_mfma_o<2,0,16>"  # the 64-column 3x3 conv on 16x16 tiles: largest share of chain time
 
 
@@ -95,6 +97,10 @@ def main() -> None:
     ap.add_argument("--frames", type=int, default=512, help="frames per GPU per step (weak scaling)")
     ap.add_argument("--chunk", type=int, default=64, help="frames per kernel chain (micro-batch of the frame loop)")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--lanes", type=int, default=2, choices=(1, 2),
+                    help="2 = odd micro-batches on the twin handle's stream (default); 1 = single stream "
+                         "(per-kernel durations under rocprofv3 are then not inflated by the other lane)")
+    ap.add_argument("--no-latency-mode", action="store_true", help="skip the 1-frame-per-launch leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -124,6 +130,7 @@ def main() -> None:
     model.to(dev).eval()
     model.set_chunk(args.chunk)
     model.set_graphs(not args.no_graphs)
+    model.set_option("dual", 1 if args.lanes == 2 else 0)
 
     F = args.frames
     n_total = F * world
@@ -165,10 +172,24 @@ def main() -> None:
             "config": {"workload": "U-Net-only 256x256 grayscale synthetic video, features (32,64,128,256), "
                                    "frame loop u8->/255->UNet->sigmoid->>0.5->area, inputs resident in HBM",
                        "frames_per_gpu_per_step": F, "frames_per_launch": args.chunk, "hip_graphs": not args.no_graphs,
+                       "lanes": args.lanes,
                        "sharding": f"frames x{world}, all_gather(int32 area) per step" if world > 1 else "none",
                        "flop_per_frame": model.flops_per_frame(256, 256)},
             "tflops": round(fps * model.flops_per_frame(256, 256) / 1e12, 2),
         }
+        # whole-chain fractions (wall clock): binding roof = f32 MFMA; HBM with SURVEY 8(d)'s layer-boundary model
+        out["chain_frac_mfma"] = round(out["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
+        out["chain_frac_hbm_layer_boundary_model"] = round(fps * LAYER_BOUNDARY_BYTES_PER_FRAME / PEAK_HBM_BYTES, 4)
+    if world == 1 and not args.no_latency_mode:
+        # BASELINE configs[1] wording "batch=1": one frame per kernel chain, frames still resident in HBM
+        n1 = min(F, 256)
+        model.set_chunk(1)
+        model.segment_dev(frames, n1, 256, 256, area); model.sync()
+        fence(); t1 = time.perf_counter()
+        model.segment_dev(frames, n1, 256, 256, area); model.sync()
+        fence(); e1 = time.perf_counter() - t1
+        out["latency_mode"] = {"frames_per_launch": 1, "value": round(n1 / e1, 1), "unit": "frames/s", "frames": n1}
+        model.set_chunk(args.chunk)
     if world == 1 and not args.no_roofline:
         B = min(args.chunk, F)
         prof = model.profile(frames, B, 256, 256, reps=max(3, min(20, args.steps)))

@@ -25,21 +25,32 @@ best = torch.empty((F, 5), dtype=torch.float32, device="cuda")
 boxes = torch.empty((F, 4), dtype=torch.int32, device="cuda")
 area = torch.zeros(F, dtype=torch.int32, device="cuda")
 
+YC = 256  # detector micro-batch
+
+def yolo_chunk(k):
+    b0 = k * YC
+    check(lib().og_yolo_detect_u8_dev(y._h, ptr(bgr[b0:]), min(YC, F - b0), 256, 256, 0.25, ptr(best[b0:]), None), "yolo")
+
 def run():
+    """Pipelined: detector chunk k+1 runs on its stream while the U-Net chain of chunk k runs on the U-Net streams;
+    the host replays the O(1)/frame temporal state machine for chunk k in between."""
     td = og.TemporalDetector(lambda f, c: None)
-    for b0 in range(0, F, 256):
-        nb = min(256, F - b0)
-        check(lib().og_yolo_detect_u8_dev(y._h, ptr(bgr[b0:]), nb, 256, 256, 0.25, ptr(best[b0:]), None), "yolo")
     check(lib().og_bgr2gray_dev(m._h, ptr(bgr), F, 256, 256, ptr(gray)), "gray")
-    check(lib().og_yolo_sync(y._h), "sync")
-    bh = best.cpu().numpy()
+    nk = (F + YC - 1) // YC
+    yolo_chunk(0)
     out = np.empty((F, 4), np.int32)
-    for i in range(F):
-        b = td.update(bh[i:i + 1, :4], bh[i:i + 1, 4], 256, 256) if bh[i, 4] >= 0 else td.update(None, None, 256, 256)
-        out[i] = normalize_box(b, 256, 256)
-    boxes.copy_(torch.from_numpy(out))
-    torch.cuda.synchronize()
-    m.segment_dev(gray, F, 256, 256, area, boxes_dev=boxes)
+    for k in range(nk):
+        check(lib().og_yolo_sync(y._h), "sync")          # chunk k's boxes are on the device
+        if k + 1 < nk:
+            yolo_chunk(k + 1)                              # overlaps with the U-Net launches below
+        b0, b1 = k * YC, min(F, (k + 1) * YC)
+        bh = np.empty((b1 - b0, 5), np.float32)
+        check(lib().og_memcpy_d2h(ptr(bh), ptr(best[b0:]), bh.nbytes), "d2h")
+        for i in range(b1 - b0):
+            b = td.update(bh[i:i + 1, :4], bh[i:i + 1, 4], 256, 256) if bh[i, 4] >= 0 else td.update(None, None, 256, 256)
+            out[b0 + i] = normalize_box(b, 256, 256)
+        check(lib().og_memcpy_h2d(ptr(boxes[b0:]), ptr(out[b0:b1]), (b1 - b0) * 16), "h2d")
+        m.segment_dev(gray[b0:], b1 - b0, 256, 256, area[b0:], boxes_dev=boxes[b0:])
     m.sync()
 
 run()
