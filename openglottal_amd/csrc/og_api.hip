@@ -371,9 +371,12 @@ inline int pick_ksplit(int n_items, int n_chunks, int slots, int ms, bool enable
 }
 
 template <int NT, int MODE, int TH, int OCC>
-int launch_conv_o(const LaunchCtx& c, const ConvArgs& a, int n_ntiles) {
+int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     constexpr int PAD = (MODE == 0) ? 1 : 0;
-    constexpr int lds = (16 + 2 * PAD) * (TH + 2 * PAD) * 128 + 2 * 32 * NT * 128;
+    constexpr int lds = ((MODE == 3) ? 18 * (TH + 1) : (16 + 2 * PAD) * (TH + 2 * PAD)) * 128 + 2 * 32 * NT * 128;
+    static_assert(lds >= 4 * 5120, "the epilogue's per-wave scratch needs 20 KB");
+    ConvArgs a = a_in;
+    a.stamps = nullptr;  // the probe buffer is sized for the persistent kernel's grid; this kernel's timeline is tools/ubench/occ_timeline
     hipLaunchKernelGGL((k_conv_mfma_o<NT, MODE, TH, OCC>), dim3(a.n_spatial * n_ntiles), dim3(256), lds, c.stream, a);
     HIPCHK(hipGetLastError());
     return OG_OK;
@@ -423,6 +426,8 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     if ((rc = set_conv_p_attr<2, 1, 8, 1>())) return rc;
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                18 * 10 * 128 + 2 * 32 * 128 + (12 * 20 + 352) * 4));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 3, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 9 * 128 + 2 * 64 * 128));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 3, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 9 * 128 + 2 * 32 * 128));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 18 * 128 + 2 * 64 * 128));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 18 * 128 + 2 * 32 * 128));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 1, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8 * 128 + 2 * 64 * 128));

@@ -98,11 +98,14 @@ struct ConvArgs {
     float* partial;         // k_splitk_epilogue sums them in split order and runs the epilogue (small-batch latency mode)
     int prio_mode;          // 0 off; 1/2: alternate s_setprio per unit, role = upper half of the grid / odd block
     unsigned long long* stamps;  // diagnostic only (nullptr in production): per workgroup
-                                 // {s_memtime, s_memrealtime} at entry and exit -> in-kernel clock
+                                 // k_conv_mfma_p: 4 x u64 {s_memtime, s_memrealtime} at entry and exit -> in-kernel clock
+                                 // k_conv_mfma_o: 8 x u64 {entry, prologue done, main loop done, stores done, HW_ID, XCC_ID}
 };
 
 // MODE 0: 3x3 conv, pad 1, stride 1  (+ per-channel affine, ReLU, optional 2x2 max-pool)
 // MODE 1: 2x2 stride-2 transposed conv as one GEMM with N = 4*Cout (dy,dx,co), scattered store
+// MODE 3 (k_conv_mfma_o only): 3x3 stride-2 pad-1 conv (YOLOv8 down-sampling Conv) as a 2x2 stride-1 conv over the
+//         space-to-depth view of the input; a.H, a.W are the OUTPUT size (input = 2H x 2W), a.n_chunks = 4 * Cin_p / 32
 // NT    : 32-column output sub-tiles per workgroup (Cout tile = 32*NT); waves are laid out (4/NT) x NT
 // TH    : tile height in pixels (tile is TH x 16)
 template <int NT, int MODE, int TH>
@@ -410,20 +413,26 @@ __global__ __launch_bounds__(256) void k_sum_counts(const int32_t* __restrict__ 
     if (threadIdx.x == 0) area[b] = s[0];
 }
 
+// 16-B slot swizzle of the halo image in k_conv_mfma_o: with the 2x2-window-major lane -> pixel order, each
+// 16-lane group of a ds_read_b128 ({0-3,12-15,20-27}, ...) touches 8 pixels of an even and 8 of an odd row; the
+// column pair index XOR 4x the row parity gives the 16 lanes 16 distinct (128-B half, slot) places -> conflict-free
+// (the linear-pixel swizzle (p >> 1) & 7 used by the other variants is 2-way conflicted on these reads).
+__device__ __forceinline__ int og_halo_swz(int py, int px) { return ((px >> 1) ^ ((py & 1) << 2)) & 7; }
+
 // Occupancy variant: ONE halo buffer (reloaded at each chunk boundary, the stall is covered by the
 // other workgroups) -> 39 KB of LDS, so 3-4 workgroups fit a CU instead of 2.  Same arithmetic and
 // accumulation order as k_conv_mfma.
 template <int NT, int MODE, int TH, int OCC, bool FIRST = false>
 __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     constexpr int TW = 16;
-    constexpr int PAD = (MODE == 0) ? 1 : 0;
-    constexpr int HW_ = TW + 2 * PAD;
-    constexpr int HH_ = TH + 2 * PAD;
+    constexpr int PAD = (MODE == 0 || MODE == 3) ? 1 : 0;                 // rows/columns of halo above / left of the tile
+    constexpr int HW_ = (MODE == 3) ? TW + 2 : TW + 2 * PAD;             // MODE 3 needs 17 columns; an even pitch keeps
+    constexpr int HH_ = (MODE == 3) ? TH + 1 : TH + 2 * PAD;             // the slot swizzle conflict-free
     constexpr int HALO_PIX = HW_ * HH_;
     constexpr int HALO_BYTES = HALO_PIX * 128;
     constexpr int HALO_PIECES = HALO_PIX * 8;
     constexpr int HALO_IT = (HALO_PIECES + 255) / 256;
-    constexpr int TAPS = (MODE == 0) ? 9 : 1;
+    constexpr int TAPS = (MODE == 0) ? 9 : (MODE == 3) ? 4 : 1;
     constexpr int WROWS = 32 * NT;
     constexpr int WBYTES = WROWS * 128;
     constexpr int WM = 4 / NT;
@@ -441,6 +450,19 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     const int wm = wave / NT;
     const int li = lane & 31;
     const int lh = lane >> 5;
+
+    // A young wave's VALU/VMEM instructions only get issue slots between the MFMAs of the older waves on its SIMD
+    // (measured: 14 k cycles from entry to the first DMA, 12 k for the epilogue, vs 17 k in the main loop of a
+    // 32-channel layer - tools/ubench/occ_timeline).  Raise the priority outside the main loop so that the address
+    // set-up, the DMA issue and the epilogue are served first; the main loops only need a slot every 64 cycles.
+    if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(3);
+    // diagnostic timeline (tools/ubench/occ_timeline.hip only; nullptr on every product path)
+    unsigned long long* const st = a.stamps ? a.stamps + 8ull * blockIdx.x : nullptr;
+    if (st != nullptr && tid == 0) {
+        st[0] = __builtin_amdgcn_s_memtime();
+        st[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID: wave slot, SIMD, CU, SE
+        st[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_REG_XCC_ID
+    }
 
     // ---- tile decode (scalar) ----
     const int n_tile = blockIdx.x / a.n_spatial;
@@ -461,26 +483,37 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     for (int it = 0; it < HALO_IT; ++it) {
         const int q = it * 256 + tid;
         const int p = q >> 3;
-        const int logical = (q & 7) ^ ((p >> 1) & 7);
         const int hy = p / HW_;
         const int hx = p - hy * HW_;
+        const int logical = (q & 7) ^ og_halo_swz(hy, hx);
         const int gy = ty0 + hy - PAD, gx = tx0 + hx - PAD;
         const bool inb = (q < HALO_PIECES) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        hsrc[it] = inb ? in_frame + ((long long)gy * a.W + gx) * a.in_pix_stride + logical * 4 : a.zero_page + logical * 4;
+        // MODE 3: (gy, gx) is a 2x2 input block = the output pixel grid; the block's (0,0) pixel is the base
+        const long long pix = (MODE == 3) ? ((long long)(2 * gy) * (2 * a.W) + 2 * gx) : ((long long)gy * a.W + gx);
+        hsrc[it] = inb ? in_frame + pix * a.in_pix_stride + logical * 4 : a.zero_page + logical * 4;
         hstep[it] = inb ? 32 : 0;
     }
     const bool last_valid = ((HALO_IT - 1) * 256 + tid) < HALO_PIECES;
 
     const unsigned lds0 = og_lds_addr(smem);
+    // MODE 3 (3x3 stride-2 conv as a 2x2 stride-1 conv over the space-to-depth view, never materialised):
+    // virtual chunk c = (input-pixel parity par = c / cpc, 32-channel chunk c % cpc)
+    const int cpc = (MODE == 3) ? a.n_chunks >> 2 : 1;
     auto stage_halo = [&](int buf, int c) {
         const unsigned base = lds0 + wave * 1024;
         (void)buf;
+        int off = c;  // in units of hstep (32 floats)
+        if (MODE == 3) {
+            const int par = c / cpc;
+            off = (((par >> 1) * 2 * a.W + (par & 1)) * a.in_pix_stride >> 5) + (c - par * cpc);  // pixel stride is a multiple of 32
+        }
 #pragma unroll
         for (int it = 0; it < HALO_IT; ++it) {
-            if (it < HALO_IT - 1 || last_valid) glds16(hsrc[it] + c * hstep[it], base + it * 4096);
+            if (it < HALO_IT - 1 || last_valid) glds16(hsrc[it] + off * hstep[it], base + it * 4096);
         }
     };
-    const float* wtile = a.wpk + (long long)n_tile * a.n_chunks * TAPS * (WROWS * 32);
+    const int total_steps = (MODE == 3) ? cpc * 9 : a.n_chunks * TAPS;  // MODE 3: only the 9 non-zero (tap, parity) pairs
+    const float* wtile = a.wpk + (long long)n_tile * total_steps * (WROWS * 32);
     auto stage_w = [&](int stage, int step) {
         const float* blk = wtile + (long long)step * (WROWS * 32) + tid * 4;
         const unsigned base = lds0 + HALO_BYTES + stage * WBYTES + wave * 1024;
@@ -502,8 +535,6 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-    const int total_steps = a.n_chunks * TAPS;
-
     if (FIRST) {
         // halo tile of the first layer's OUTPUT, computed here: 12x20 u8 patch -> /255 -> 3x3 conv -> BN -> ReLU,
         // written in the same swizzled [pixel][8 x 16 B] image the LDS-DMA would have produced
@@ -523,8 +554,8 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
             const int q = it * 256 + tid;
             if (q < HALO_PIECES) {
                 const int p = q >> 3;
-                const int c0 = ((q & 7) ^ ((p >> 1) & 7)) * 4;
                 const int hy = p / HW_, hx = p - hy * HW_;
+                const int c0 = ((q & 7) ^ og_halo_swz(hy, hx)) * 4;
                 const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};   // outside the image: the second conv's zero padding
                 if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
@@ -548,28 +579,36 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
             }
         }
     } else {
+        if (st != nullptr && tid == 0) st[6] = __builtin_amdgcn_s_memtime();
         stage_halo(0, 0);
         stage_w(0, 0);
     }
     og_wait_dma();
+    if (st != nullptr && tid == 0) st[7] = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    if (st != nullptr && tid == 0) st[1] = __builtin_amdgcn_s_memtime();
+    if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(0);
 
     int step = 0;
     for (int c = 0; c < a.n_chunks; ++c) {
         const unsigned char* hb = halo0;
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t, ++step) {
+        for (int t = 0; t < TAPS; ++t) {
+            if (MODE == 3) {  // tap (ty,tx) of the 2x2 kernel meets parity (py,px): zero unless (ty==1 || py==1) and (tx==1 || px==1)
+                const int par = c / cpc;
+                if (((t >> 1) == 0 && (par & 2) == 0) || ((t & 1) == 0 && (par & 1) == 0)) continue;
+            }
             if (step + 1 < total_steps) stage_w((step + 1) & 1, step + 1);
 
             const unsigned char* wb = wbuf0 + (step & 1) * WBYTES;
-            const int dy = (MODE == 0) ? t / 3 : 0;
-            const int dx = (MODE == 0) ? t % 3 : 0;
+            const int dy = (MODE == 0) ? t / 3 : (MODE == 3) ? (t >> 1) : 0;
+            const int dx = (MODE == 0) ? t % 3 : (MODE == 3) ? (t & 1) : 0;
             int aoff[MS];
 #pragma unroll
             for (int m = 0; m < MS; ++m) {
                 const int py = 2 * (wm * MS + m) + pyl + dy;
                 const int p = py * HW_ + px0 + dx;
-                aoff[m] = p * 128 + ((lh ^ ((p >> 1) & 7)) << 4);
+                aoff[m] = p * 128 + ((lh ^ og_halo_swz(py, px0 + dx)) << 4);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -586,6 +625,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
             }
             og_wait_dma();
             __syncthreads();
+            ++step;
         }
         if (c + 1 < a.n_chunks) {  // every read of the halo buffer completed before the barrier above
             stage_halo(0, c + 1);
@@ -594,11 +634,17 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
         }
     }
 
+    if (st != nullptr && tid == 0) st[2] = __builtin_amdgcn_s_memtime();
+    if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(3);
     // ---- epilogue (all staging buffers are dead behind the last barrier: LDS is scratch now) ----
     {
         const int ncol = n_tile * WROWS + wn * 32 + li;
         const int co = (MODE == 1) ? ncol % a.aff_mod : ncol;
         conv_epilogue<NT, MODE, TH>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, a.scale[co], a.shift[co], smem + wave * 5120);
+    }
+    if (st != nullptr && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st[3] = __builtin_amdgcn_s_memtime();
     }
 }
 
