@@ -12,7 +12,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libopenglottal_hip.so")
+# OPENGLOTTAL_HIP_LIB: load another build of the same C-ABI (A/B builds, an installed copy)
+LIB_PATH = os.environ.get("OPENGLOTTAL_HIP_LIB") or os.path.join(_HERE, "libopenglottal_hip.so")
 
 OG_DTYPE_F32, OG_DTYPE_I64 = 0, 1
 

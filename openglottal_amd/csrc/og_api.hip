@@ -370,10 +370,17 @@ inline int pick_ksplit(int n_items, int n_chunks, int slots, int ms, bool enable
     return k < 1 ? 1 : k;
 }
 
+// LDS of k_conv_mfma_o: one halo buffer + the weight ring (3 stages for the 3x3 conv, 2 otherwise)
+template <int NT, int MODE, int TH>
+constexpr int conv_o_lds() {
+    return ((MODE == 3) ? 18 * (TH + 1) : (16 + 2 * ((MODE == 0) ? 1 : 0)) * (TH + 2 * ((MODE == 0) ? 1 : 0))) * 128 +
+           ((MODE == 0) ? 3 : 2) * 32 * NT * 128;
+}
+
 template <int NT, int MODE, int TH, int OCC>
 int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     constexpr int PAD = (MODE == 0) ? 1 : 0;
-    constexpr int lds = ((MODE == 3) ? 18 * (TH + 1) : (16 + 2 * PAD) * (TH + 2 * PAD)) * 128 + 2 * 32 * NT * 128;
+    constexpr int lds = conv_o_lds<NT, MODE, TH>();
     static_assert(lds >= 4 * 5120, "the epilogue's per-wave scratch needs 20 KB");
     ConvArgs a = a_in;
     a.stamps = nullptr;  // the probe buffer is sized for the persistent kernel's grid; this kernel's timeline is tools/ubench/occ_timeline
@@ -425,16 +432,16 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     if ((rc = set_conv_p_attr<1, 0, 8, 9>())) return rc;
     if ((rc = set_conv_p_attr<2, 1, 8, 1>())) return rc;
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               18 * 10 * 128 + 2 * 32 * 128 + (12 * 20 + 352) * 4));
-    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 3, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 9 * 128 + 2 * 64 * 128));
-    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 3, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 9 * 128 + 2 * 32 * 128));
-    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 18 * 128 + 2 * 64 * 128));
-    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 18 * 128 + 2 * 32 * 128));
-    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 1, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8 * 128 + 2 * 64 * 128));
-    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 10 * 128 + 2 * 64 * 128));
-    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 10 * 128 + 2 * 32 * 128));
-    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 10 * 128 + 2 * 64 * 128));
-    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 10 * 128 + 2 * 32 * 128));
+                               conv_o_lds<1, 0, 8>() + (12 * 20 + 352) * 4));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 3, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 3, 8>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 3, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 3, 8>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 16>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 16>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 1, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 1, 8>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 8>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 8>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 8>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 8>()));
     if ((rc = set_conv_p_attr<2, 0, 16, 1>())) return rc;
     if ((rc = set_conv_p_attr<2, 0, 16, 3>())) return rc;
     if ((rc = set_conv_p_attr<1, 0, 16, 3>())) return rc;
@@ -671,7 +678,7 @@ int enqueue_first_fused(og_unet* h, const uint8_t* gray, int B, int H, int W) {
     a.first_w9 = h->d_first_w;
     a.first_scale = h->d_first_scale;
     a.first_shift = h->d_first_shift;
-    constexpr int lds = 18 * 10 * 128 + 2 * 32 * 128 + (12 * 20 + 352) * 4;
+    constexpr int lds = conv_o_lds<1, 0, 8>() + (12 * 20 + 352) * 4;
     prof_begin(h, "downs.0 (first + second conv fused)", "k_conv_mfma_o<1,0,8,FIRST>",
                2.0 * B * H * W * 9.0 * (1.0 * h->features[0] + (double)h->features[0] * h->features[0]));
     hipLaunchKernelGGL((k_conv_mfma_o<1, 0, 8, 3, true>), dim3(a.n_spatial), dim3(256), lds, h->stream, a);

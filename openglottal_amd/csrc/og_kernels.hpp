@@ -41,6 +41,37 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_wave_base
         : "v"(gsrc), "s"(lds_wave_base)
         : "memory");
 }
+// The same transfer addressed through a buffer resource: 32-bit per-lane byte offset + wave-uniform byte offset
+// in an SGPR.  Two things the flat form cannot do: (1) the per-chunk / per-step advance lives in the SGPR, so a
+// stage costs no vector ALU instruction at all (each one takes matrix-pipe time: tools/ubench/mfma_valu_coexec);
+// (2) a lane whose offset is >= num_records reads zeros, which is the conv's zero padding without a zero page
+// and without a per-lane select.
+typedef int og_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ og_i32x4 og_make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    og_i32x4 r;
+    r.x = (int)(unsigned)b;
+    r.y = (int)(unsigned)(b >> 32) & 0xFFFF;  // stride 0: raw buffer
+    r.z = (int)bytes;                          // num_records (bytes)
+    r.w = 0x00020000;                          // DATA_FORMAT 32, untyped access
+    r.x = __builtin_amdgcn_readfirstlane(r.x);
+    r.y = __builtin_amdgcn_readfirstlane(r.y);
+    r.z = __builtin_amdgcn_readfirstlane(r.z);
+    return r;
+}
+constexpr unsigned OG_OOB = 0x80000000u;  // a lane offset no buffer of < 2 GiB contains
+__device__ __forceinline__ void glds16b(unsigned voff, og_i32x4 rsrc, unsigned soff, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_wave_base)
+        : "memory");
+}
 __device__ __forceinline__ float og_act(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
     if (act == 2) return v / (1.0f + expf(-v));  // SiLU = x * sigmoid(x)
@@ -435,6 +466,9 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     constexpr int TAPS = (MODE == 0) ? 9 : (MODE == 3) ? 4 : 1;
     constexpr int WROWS = 32 * NT;
     constexpr int WBYTES = WROWS * 128;
+    // weight ring: 3 stages for the 3x3 conv, so that a tap's stage (t % 3, nine taps per chunk) is a compile-time
+    // constant and the B-fragment reads need no address arithmetic; 2 stages (runtime parity) elsewhere
+    constexpr int NSTG = (MODE == 0) ? 3 : 2;
     constexpr int WM = 4 / NT;
     constexpr int MS = (TH / 2) / WM;  // 32-row M sub-tiles (2 pixel rows x 16) per wave
     static_assert(MS >= 1, "tile too small");
@@ -474,24 +508,29 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     const int ty0 = tyi * TH;
     const int tx0 = (sp - tyi * a.tiles_x) * TW;
 
-    const float* in_frame = a.in + (long long)b * a.in_frame_stride + a.in_ch_off;
+    // this frame's input as a raw buffer: offsets past num_records read as zeros (= the conv's zero padding)
+    const og_i32x4 in_rsrc = og_make_rsrc(a.in + (long long)b * a.in_frame_stride + a.in_ch_off,
+                                          (unsigned)(a.in_frame_stride - a.in_ch_off) * 4u);
 
-    // ---- per-thread halo source pointers (fixed across channel chunks) ----
-    const float* hsrc[HALO_IT];
-    int hstep[HALO_IT];
+    // ---- per-thread halo source offsets (bytes, fixed across channel chunks); pixel index walks incrementally ----
+    unsigned hoff[HALO_IT];
+    {
+        int hy = ((tid >> 3) >= HW_) ? 1 : 0;
+        int hx = (tid >> 3) - hy * HW_;
+        const int in_w = (MODE == 3) ? 2 * a.W : a.W;
+        const int row_b = in_w * a.in_pix_stride * ((MODE == 3) ? 8 : 4);   // bytes per halo row step
+        const int col_b = a.in_pix_stride * ((MODE == 3) ? 8 : 4);          // bytes per halo column step
 #pragma unroll
-    for (int it = 0; it < HALO_IT; ++it) {
-        const int q = it * 256 + tid;
-        const int p = q >> 3;
-        const int hy = p / HW_;
-        const int hx = p - hy * HW_;
-        const int logical = (q & 7) ^ og_halo_swz(hy, hx);
-        const int gy = ty0 + hy - PAD, gx = tx0 + hx - PAD;
-        const bool inb = (q < HALO_PIECES) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        // MODE 3: (gy, gx) is a 2x2 input block = the output pixel grid; the block's (0,0) pixel is the base
-        const long long pix = (MODE == 3) ? ((long long)(2 * gy) * (2 * a.W) + 2 * gx) : ((long long)gy * a.W + gx);
-        hsrc[it] = inb ? in_frame + pix * a.in_pix_stride + logical * 4 : a.zero_page + logical * 4;
-        hstep[it] = inb ? 32 : 0;
+        for (int it = 0; it < HALO_IT; ++it) {
+            const int logical = (tid & 7) ^ og_halo_swz(hy, hx);
+            const int gy = ty0 + hy - PAD, gx = tx0 + hx - PAD;
+            // MODE 3: (gy, gx) is a 2x2 input block = the output pixel grid; the block's (0,0) pixel is the base
+            const bool inb = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            hoff[it] = inb ? (unsigned)(gy * row_b + gx * col_b + logical * 16) : OG_OOB;
+            hx += 32 % HW_;
+            hy += 32 / HW_;
+            if (hx >= HW_) { hx -= HW_; hy += 1; }
+        }
     }
     const bool last_valid = ((HALO_IT - 1) * 256 + tid) < HALO_PIECES;
 
@@ -502,23 +541,23 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     auto stage_halo = [&](int buf, int c) {
         const unsigned base = lds0 + wave * 1024;
         (void)buf;
-        int off = c;  // in units of hstep (32 floats)
+        unsigned soff = (unsigned)c * 128u;  // wave-uniform byte offset of the chunk
         if (MODE == 3) {
             const int par = c / cpc;
-            off = (((par >> 1) * 2 * a.W + (par & 1)) * a.in_pix_stride >> 5) + (c - par * cpc);  // pixel stride is a multiple of 32
+            soff = (unsigned)((((par >> 1) * 2 * a.W + (par & 1)) * a.in_pix_stride + (c - par * cpc) * 32) * 4);
         }
 #pragma unroll
         for (int it = 0; it < HALO_IT; ++it) {
-            if (it < HALO_IT - 1 || last_valid) glds16(hsrc[it] + off * hstep[it], base + it * 4096);
+            if (it < HALO_IT - 1 || last_valid) glds16b(hoff[it], in_rsrc, soff, base + it * 4096);
         }
     };
     const int total_steps = (MODE == 3) ? cpc * 9 : a.n_chunks * TAPS;  // MODE 3: only the 9 non-zero (tap, parity) pairs
-    const float* wtile = a.wpk + (long long)n_tile * total_steps * (WROWS * 32);
+    const og_i32x4 w_rsrc = og_make_rsrc(a.wpk + (long long)n_tile * total_steps * (WROWS * 32), (unsigned)total_steps * WBYTES);
+    const unsigned woff = (unsigned)tid * 16u;
     auto stage_w = [&](int stage, int step) {
-        const float* blk = wtile + (long long)step * (WROWS * 32) + tid * 4;
         const unsigned base = lds0 + HALO_BYTES + stage * WBYTES + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) glds16(blk + i * 1024, base + i * 4096);
+        for (int i = 0; i < NT; ++i) glds16b(woff, w_rsrc, (unsigned)step * WBYTES + i * 4096, base + i * 4096);
     };
 
     // ---- fragment addressing ----
@@ -528,6 +567,19 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     const int pyl = (li >> 1) & 1;
     const int brow = wn * 32 + li;
     const int boff = brow * 128 + ((lh ^ ((brow >> 1) & 7)) << 4);
+    // Everything lane-dependent of an A-fragment address sits in NDX x 4 registers:
+    //   abase[dx][pat] = ((pyl*HW_ + px0+dx) * 128 + ((lh ^ swz(pyl, px0+dx)) << 4) + wave row offset) ^ (pat << 5)
+    // and a tap's dy, the k-group j and the M sub-tile m only select pat = j ^ ((dy & 1) << 1) (row parity flips slot
+    // bit 2) and add the compile-time constant (dy + 2m) * HW_ * 128, which the ds_read carries as its immediate.
+    constexpr int NDX = (MODE == 0) ? 3 : (MODE == 3) ? 2 : 1;
+    unsigned abase[NDX][4];
+#pragma unroll
+    for (int dx = 0; dx < NDX; ++dx) {
+        const int px = px0 + dx;
+        const unsigned o = (unsigned)((pyl * HW_ + px) * 128 + ((lh ^ og_halo_swz(pyl, px)) << 4) + wm * (MS * 2 * HW_ * 128));
+#pragma unroll
+        for (int pat = 0; pat < 4; ++pat) abase[dx][pat] = o ^ (unsigned)(pat << 5);
+    }
 
     f32x16 acc[MS];
 #pragma unroll
@@ -538,7 +590,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     if (FIRST) {
         // halo tile of the first layer's OUTPUT, computed here: 12x20 u8 patch -> /255 -> 3x3 conv -> BN -> ReLU,
         // written in the same swizzled [pixel][8 x 16 B] image the LDS-DMA would have produced
-        float* patch = (float*)(smem + HALO_BYTES + 2 * WBYTES);  // [HH_+2][HW_+2]
+        float* patch = (float*)(smem + HALO_BYTES + NSTG * WBYTES);  // [HH_+2][HW_+2]
         float* fw = patch + (HH_ + 2) * (HW_ + 2);                // w9[9][32] | scale[32] | shift[32]
         const uint8_t* fin = a.first_u8 + (long long)b * a.H * a.W;
         for (int i = tid; i < (HH_ + 2) * (HW_ + 2); i += 256) {
@@ -598,25 +650,19 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
                 const int par = c / cpc;
                 if (((t >> 1) == 0 && (par & 2) == 0) || ((t & 1) == 0 && (par & 1) == 0)) continue;
             }
-            if (step + 1 < total_steps) stage_w((step + 1) & 1, step + 1);
+            const int stg = (MODE == 0) ? t % 3 : (step & 1), stg_next = (MODE == 0) ? (t + 1) % 3 : ((step + 1) & 1);
+            if (step + 1 < total_steps) stage_w(stg_next, step + 1);
 
-            const unsigned char* wb = wbuf0 + (step & 1) * WBYTES;
+            const unsigned char* wb = wbuf0 + stg * WBYTES;
             const int dy = (MODE == 0) ? t / 3 : (MODE == 3) ? (t >> 1) : 0;
             const int dx = (MODE == 0) ? t % 3 : (MODE == 3) ? (t & 1) : 0;
-            int aoff[MS];
-#pragma unroll
-            for (int m = 0; m < MS; ++m) {
-                const int py = 2 * (wm * MS + m) + pyl + dy;
-                const int p = py * HW_ + px0 + dx;
-                aoff[m] = p * 128 + ((lh ^ og_halo_swz(py, px0 + dx)) << 4);
-            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // slot = (2j + lh) ^ swz  ==  ((lh ^ swz) << 4) ^ (j << 5) in bytes
                 const f32x4 bv = *(const f32x4*)(wb + (boff ^ (j << 5)));
 #pragma unroll
                 for (int m = 0; m < MS; ++m) {
-                    const f32x4 av = *(const f32x4*)(hb + (aoff[m] ^ (j << 5)));
+                    const f32x4 av = *(const f32x4*)(hb + abase[dx][j ^ ((dy & 1) << 1)] + (dy + 2 * m) * (HW_ * 128));
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[m], 0, 0, 0);
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[m], 0, 0, 0);
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[m], 0, 0, 0);

@@ -53,15 +53,15 @@ int main(int argc, char** argv) {
         a.stamps = (rep == 3) ? dst : nullptr;
         CK(hipEventRecord(e0));
         if (var == "n1") {
-            const int lds = 18 * 10 * 128 + 2 * 32 * 128;
+            const int lds = 18 * 10 * 128 + 3 * 32 * 128;
             CK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             hipLaunchKernelGGL((k_conv_mfma_o<1, 0, 8, 3>), dim3(grid), dim3(256), lds, 0, a);
         } else if (var == "n2t8") {
-            const int lds = 18 * 10 * 128 + 2 * 64 * 128;
+            const int lds = 18 * 10 * 128 + 3 * 64 * 128;
             CK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             hipLaunchKernelGGL((k_conv_mfma_o<2, 0, 8, 3>), dim3(grid), dim3(256), lds, 0, a);
         } else {
-            const int lds = 18 * 18 * 128 + 2 * 64 * 128;
+            const int lds = 18 * 18 * 128 + 3 * 64 * 128;
             CK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             hipLaunchKernelGGL((k_conv_mfma_o<2, 0, 16, 2>), dim3(grid), dim3(256), lds, 0, a);
         }
