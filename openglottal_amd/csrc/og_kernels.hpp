@@ -429,6 +429,163 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16* a
     }
 }
 
+// Lean epilogue of k_conv_mfma_o.  Same arithmetic, element order and results as conv_epilogue, but written so
+// that almost no vector-ALU instruction is spent on addressing (each one costs the SIMD matrix-pipe time):
+//  * every global access goes through a raw buffer resource: the lane-dependent byte offset is computed ONCE per
+//    wave, the (sub-tile, row group) advance is a wave-uniform SGPR offset, and lanes outside the image carry the
+//    offset OG_OOB, which the bounds check drops -- no per-store address arithmetic, no exec masking;
+//  * activation and residual are template parameters (no per-element uniform branches);
+//  * the fused head evaluates sigmoid / threshold / box test once per 32-pixel sub-tile (one pixel per lane) and
+//    counts with a ballot + scalar popcount instead of four 8-pixel rounds and a shuffle reduction.
+typedef unsigned og_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t og_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long v = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+template <int NT, int MODE, int TH, int ACT, bool RES>
+__device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16* acc, int n_tile, int b, int ty0, int tx0, int wm, int wn,
+                                                int li, int lh, float sc, float sh, unsigned char* scratch) {
+    constexpr int WROWS = 32 * NT;
+    constexpr int WM = 4 / NT;
+    constexpr int MS = (TH / 2) / WM;
+    const int lane = li + 32 * lh;
+    const int ncol0 = n_tile * WROWS + wn * 32;
+    int cbase = ncol0, qd = 0;
+    if (MODE == 1) {
+        qd = ncol0 / a.aff_mod;
+        cbase = ncol0 - qd * a.aff_mod;
+    }
+    const int OW = (MODE == 1) ? 2 * a.W : a.W;
+    // read-back role of this lane: pixel row (rrow + 8q) of the 32-row sub-tile, channels rc4..rc4+3
+    const int rrow = lane >> 3, rc4 = (lane & 7) * 4;
+    const int xl = 2 * (rrow >> 2) + (rrow & 1), yl = (rrow & 3) >> 1;  // pixel inside the (2 rows x 16 columns) sub-tile: x = xl + 4q
+    const bool fuse_head = (MODE == 0 && NT == 1 && a.head_w != nullptr);
+    const bool store_act = !fuse_head || a.head_store_act;
+
+    const __amdgpu_buffer_rsrc_t out_rs = og_rsrc(a.out + (long long)b * a.out_frame_stride, (unsigned)a.out_frame_stride * 4u);
+    const unsigned lp = (MODE == 1) ? (unsigned)(((2 * yl * OW + 2 * xl) * a.out_pix_stride + rc4) * 4)
+                                    : (unsigned)(((yl * OW + xl) * a.out_pix_stride + rc4) * 4);
+    unsigned vq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) vq[q] = (tx0 + xl + 4 * q < a.W) ? lp : OG_OOB;
+
+    // accumulator-layout role: channel li, pixel rows 8g + 4lh + rr
+    float* const fw = (float*)scratch + (128 * lh + li);            // + (8g + rr) * 32
+    const float* const fr = (const float*)scratch + rrow * 32 + rc4;  // + q * 256
+    __amdgpu_buffer_rsrc_t res_rs = out_rs, pool_rs = out_rs;
+    unsigned vres[4] = {0, 0, 0, 0}, vpool = 0;
+    if (RES) {
+        res_rs = og_rsrc(a.res + (long long)b * a.res_frame_stride, (unsigned)a.res_frame_stride * 4u);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) vres[g] = (tx0 + 4 * g + 2 * lh < a.W) ? (unsigned)((2 * lh * a.res_pix_stride + li) * 4) : OG_OOB;
+    }
+    const bool pool = (MODE == 0 && a.pool != nullptr);
+    if (pool) {
+        pool_rs = og_rsrc(a.pool + (long long)b * a.pool_frame_stride, (unsigned)a.pool_frame_stride * 4u);
+        vpool = (tx0 + 2 * rrow < a.W) ? (unsigned)((rrow * a.pool_pix_stride + rc4) * 4) : OG_OOB;
+    }
+    // fused head: weights of this lane's 4 channels, loaded once ahead of every store; one pixel per lane k < 4
+    f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+    int hbx1 = 0, hby1 = 0, hbx2 = 1 << 30, hby2 = 1 << 30, head_cnt = 0;
+    const int hk = lane & 7;
+    unsigned vh = OG_OOB;  // pixel offset (elements) of this lane's head pixel inside the frame, relative to the sub-tile origin
+    if (fuse_head) {
+        wv = *(const f32x4*)(a.head_w + rc4);
+        if (a.head_boxes != nullptr) {
+            hbx1 = a.head_boxes[b * 4 + 0];
+            hby1 = a.head_boxes[b * 4 + 1];
+            hbx2 = a.head_boxes[b * 4 + 2];
+            hby2 = a.head_boxes[b * 4 + 3];
+            if (hbx1 < 0) { hbx1 = hby1 = hbx2 = hby2 = 0; }  // "no detection" -> area 0 (features.py:241-242)
+        }
+        if (hk < 4 && tx0 + xl + 4 * hk < a.W) vh = (unsigned)(yl * a.W + xl + 4 * hk);
+    }
+
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+        const int ms = wm * MS + m;
+        const int y0 = ty0 + 2 * ms;          // first of this sub-tile's two pixel rows (H is even: both inside or both outside)
+        float vmaxs[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float v = fmaf(acc[m][4 * g + rr], sc, sh);
+                if (ACT == 1) v = fmaxf(v, 0.f);
+                if (ACT == 2) v = v / (1.0f + expf(-v));
+                if (RES) {
+                    const unsigned so = (unsigned)((((y0 + (rr >> 1)) * OW + tx0 + 4 * g + (rr & 1)) * a.res_pix_stride + a.res_ch_off + cbase) * 4);
+                    const float r = __builtin_amdgcn_raw_buffer_load_b32(res_rs, (y0 + (rr >> 1) < a.H) ? vres[g] : OG_OOB, so, 0);
+                    v += r;
+                }
+                fw[(8 * g + rr) * 32] = v;
+                vmaxs[g] = (rr == 0) ? v : fmaxf(vmaxs[g], v);
+            }
+        }
+        f32x4 v4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v4[q] = *(const f32x4*)(fr + q * 256);
+        if (y0 < a.H) {
+            const bool half = (y0 + 1 >= a.H);   // odd H (detector maps of 160-pixel inputs): only the first row exists
+            if (store_act) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int so = (MODE == 1) ? (((2 * y0 + (qd >> 1)) * OW + 2 * (tx0 + 4 * q) + (qd & 1)) * a.out_pix_stride + a.out_ch_off + cbase) * 4
+                                               : ((y0 * OW + tx0 + 4 * q) * a.out_pix_stride + a.out_ch_off + cbase) * 4;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(og_u32x4, v4[q]), out_rs, (half && yl) ? OG_OOB : vq[q], so, 0);
+                }
+            }
+            if (MODE == 0 && NT == 1 && fuse_head) {
+                float sd[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float sdot = 0.f;
+                    sdot = fmaf(v4[q].x, wv.x, sdot);
+                    sdot = fmaf(v4[q].y, wv.y, sdot);
+                    sdot = fmaf(v4[q].z, wv.z, sdot);
+                    sdot = fmaf(v4[q].w, wv.w, sdot);
+                    sdot += __shfl_xor(sdot, 1);
+                    sdot += __shfl_xor(sdot, 2);
+                    sdot += __shfl_xor(sdot, 4);
+                    sd[q] = sdot;   // every lane of the 8-lane group holds the pixel's sum
+                }
+                const float mine = (hk == 0) ? sd[0] : (hk == 1) ? sd[1] : (hk == 2) ? sd[2] : sd[3];  // lane k < 4: pixel row rrow + 8k
+                const float lg = mine + a.head_bias;
+                const float prob = 1.0f / (1.0f + expf(-lg));
+                const bool on = prob > a.head_thr;
+                const int x = tx0 + xl + 4 * hk, y = y0 + yl;
+                const bool counted = on && vh != OG_OOB && x >= hbx1 && x < hbx2 && y >= hby1 && y < hby2;
+                head_cnt += __builtin_popcountll(__ballot(counted));
+                const unsigned so = (unsigned)(y0 * a.W + tx0);
+                if (a.head_logits) {
+                    const __amdgpu_buffer_rsrc_t lrs = og_rsrc(a.head_logits + (long long)b * a.H * a.W, (unsigned)(a.H * a.W) * 4u);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lg), lrs, (vh == OG_OOB) ? OG_OOB : vh * 4u, so * 4u, 0);
+                }
+                if (a.head_mask) {
+                    const __amdgpu_buffer_rsrc_t mrs = og_rsrc(a.head_mask + (long long)b * a.H * a.W, (unsigned)(a.H * a.W));
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(on ? 255 : 0), mrs, vh, so, 0);
+                }
+            }
+            if (pool) {
+                // pooled tile: 8 windows x 32 channels = exactly one 16-B store per lane
+#pragma unroll
+                for (int g = 0; g < 4; ++g) fw[1024 - 96 * lh + g * 64] = vmaxs[g];  // fs[1024 + (2g + lh) * 32 + li]
+                const f32x4 p4 = *(const f32x4*)(fr + 1024);
+                const int so = (((y0 >> 1) * (a.W >> 1) + (tx0 >> 1)) * a.pool_pix_stride + a.pool_ch_off + cbase) * 4;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(og_u32x4, p4), pool_rs, vpool, so, 0);
+            }
+        }
+    }
+    if (MODE == 0 && NT == 1 && fuse_head && a.head_area != nullptr) {
+        // one plain store per wave into a per-(frame, tile, wave) slot; k_sum_counts adds them up per frame
+        if (lane == 0) {
+            const int tile = (ty0 / TH) * a.tiles_x + (tx0 >> 4);
+            a.head_area[((long long)b * a.tiles_x * a.tiles_y + tile) * 4 + (wm * NT + wn)] = head_cnt;
+        }
+    }
+}
+
 // Per-frame sum of the fused head's per-(tile, wave) pixel counts -> area[b]  (features.py:238 / 244-245).
 __global__ __launch_bounds__(256) void k_sum_counts(const int32_t* __restrict__ counts, int per_frame, int32_t* __restrict__ area) {
     __shared__ int s[256];
@@ -686,7 +843,11 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     {
         const int ncol = n_tile * WROWS + wn * 32 + li;
         const int co = (MODE == 1) ? ncol % a.aff_mod : ncol;
-        conv_epilogue<NT, MODE, TH>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, a.scale[co], a.shift[co], smem + wave * 5120);
+        unsigned char* const scr = smem + wave * 5120;
+        if (a.act == 1) conv_epilogue_b<NT, MODE, TH, 1, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, a.scale[co], a.shift[co], scr);
+        else if (a.act == 2 && a.res != nullptr) conv_epilogue_b<NT, MODE, TH, 2, true>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, a.scale[co], a.shift[co], scr);
+        else if (a.act == 2) conv_epilogue_b<NT, MODE, TH, 2, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, a.scale[co], a.shift[co], scr);
+        else conv_epilogue_b<NT, MODE, TH, 0, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, a.scale[co], a.shift[co], scr);
     }
     if (st != nullptr && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
