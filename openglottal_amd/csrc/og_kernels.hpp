@@ -46,6 +46,11 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_wave_base
 // stage costs no vector ALU instruction at all (each one takes matrix-pipe time: tools/ubench/mfma_valu_coexec);
 // (2) a lane whose offset is >= num_records reads zeros, which is the conv's zero padding without a zero page
 // and without a per-lane select.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two fused multiply-adds in one vector-ALU instruction (v_pk_fma_f32); each component is an ordinary fmaf
+__device__ __forceinline__ f32x2 og_fma2s(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+__device__ __forceinline__ f32x2 og_fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#define og_fma2_first og_fma2
 typedef int og_i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ og_i32x4 og_make_rsrc(const void* base, unsigned bytes) {
     const unsigned long long b = (unsigned long long)base;
@@ -507,11 +512,17 @@ __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16*
         const int ms = wm * MS + m;
         const int y0 = ty0 + 2 * ms;          // first of this sub-tile's two pixel rows (H is even: both inside or both outside)
         float vmaxs[4];
+        const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            // scalar fmas on purpose: with v_pk_fma_f32 here the ReLU layers stayed bit-exact but a few lanes of the
+            // ACT 0 (transposed conv) and ACT 2 (SiLU) outputs came out wrong on gfx950 (tools/dbg_layers.py); the
+            // packed form is kept only in the fused first layer, where the variant test pins it bit for bit
+            const f32x2 a01 = og_fma2s(f32x2{acc[m][4 * g], acc[m][4 * g + 1]}, sc2, sh2);
+            const f32x2 a23 = og_fma2s(f32x2{acc[m][4 * g + 2], acc[m][4 * g + 3]}, sc2, sh2);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                float v = fmaf(acc[m][4 * g + rr], sc, sh);
+                float v = (rr == 0) ? a01.x : (rr == 1) ? a01.y : (rr == 2) ? a23.x : a23.y;
                 if (ACT == 1) v = fmaxf(v, 0.f);
                 if (ACT == 2) v = v / (1.0f + expf(-v));
                 if (RES) {
@@ -738,6 +749,11 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
         for (int pat = 0; pat < 4; ++pat) abase[dx][pat] = o ^ (unsigned)(pat << 5);
     }
 
+    // this lane's output channel: folded BN scale / shift, loaded now so that the epilogue does not wait for them
+    const int ecol = n_tile * WROWS + wn * 32 + li;
+    const int eco = (MODE == 1) ? ecol % a.aff_mod : ecol;
+    const float esc = a.scale[eco], esh = a.shift[eco];
+
     f32x16 acc[MS];
 #pragma unroll
     for (int m = 0; m < MS; ++m)
@@ -768,21 +784,22 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
                 const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};   // outside the image: the second conv's zero padding
                 if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+                    f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};   // same fma chain per channel, two channels per instruction
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
                         const float xv = patch[(hy + t / 3) * (HW_ + 2) + hx + t % 3];
                         const f32x4 wv = *(const f32x4*)(fw + t * 32 + c0);
-                        sacc.x = fmaf(xv, wv.x, sacc.x);
-                        sacc.y = fmaf(xv, wv.y, sacc.y);
-                        sacc.z = fmaf(xv, wv.z, sacc.z);
-                        sacc.w = fmaf(xv, wv.w, sacc.w);
+                        const f32x2 x2 = {xv, xv};
+                        s01 = og_fma2_first(x2, f32x2{wv.x, wv.y}, s01);
+                        s23 = og_fma2_first(x2, f32x2{wv.z, wv.w}, s23);
                     }
                     const f32x4 sc4 = *(const f32x4*)(fw + 288 + c0), sh4 = *(const f32x4*)(fw + 320 + c0);
-                    o.x = fmaxf(fmaf(sacc.x, sc4.x, sh4.x), 0.f);
-                    o.y = fmaxf(fmaf(sacc.y, sc4.y, sh4.y), 0.f);
-                    o.z = fmaxf(fmaf(sacc.z, sc4.z, sh4.z), 0.f);
-                    o.w = fmaxf(fmaf(sacc.w, sc4.w, sh4.w), 0.f);
+                    s01 = og_fma2_first(s01, f32x2{sc4.x, sc4.y}, f32x2{sh4.x, sh4.y});
+                    s23 = og_fma2_first(s23, f32x2{sc4.z, sc4.w}, f32x2{sh4.z, sh4.w});
+                    o.x = fmaxf(s01.x, 0.f);
+                    o.y = fmaxf(s01.y, 0.f);
+                    o.z = fmaxf(s23.x, 0.f);
+                    o.w = fmaxf(s23.y, 0.f);
                 }
                 *(f32x4*)(halo0 + q * 16) = o;
             }
@@ -841,13 +858,11 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(3);
     // ---- epilogue (all staging buffers are dead behind the last barrier: LDS is scratch now) ----
     {
-        const int ncol = n_tile * WROWS + wn * 32 + li;
-        const int co = (MODE == 1) ? ncol % a.aff_mod : ncol;
         unsigned char* const scr = smem + wave * 5120;
-        if (a.act == 1) conv_epilogue_b<NT, MODE, TH, 1, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, a.scale[co], a.shift[co], scr);
-        else if (a.act == 2 && a.res != nullptr) conv_epilogue_b<NT, MODE, TH, 2, true>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, a.scale[co], a.shift[co], scr);
-        else if (a.act == 2) conv_epilogue_b<NT, MODE, TH, 2, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, a.scale[co], a.shift[co], scr);
-        else conv_epilogue_b<NT, MODE, TH, 0, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, a.scale[co], a.shift[co], scr);
+        if (a.act == 1) conv_epilogue_b<NT, MODE, TH, 1, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+        else if (a.act == 2 && a.res != nullptr) conv_epilogue_b<NT, MODE, TH, 2, true>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+        else if (a.act == 2) conv_epilogue_b<NT, MODE, TH, 2, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+        else conv_epilogue_b<NT, MODE, TH, 0, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
     }
     if (st != nullptr && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
