@@ -824,7 +824,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
                 const int par = c / cpc;
                 if (((t >> 1) == 0 && (par & 2) == 0) || ((t & 1) == 0 && (par & 1) == 0)) continue;
             }
-            const int stg = (MODE == 0) ? t % 3 : (step & 1), stg_next = (MODE == 0) ? (t + 1) % 3 : ((step + 1) & 1);
+            const int stg = (NSTG == 3) ? t % 3 : (step & 1), stg_next = (NSTG == 3) ? (t + 1) % 3 : ((step + 1) & 1);
             if (step + 1 < total_steps) stage_w(stg_next, step + 1);
 
             const unsigned char* wb = wbuf0 + stg * WBYTES;
