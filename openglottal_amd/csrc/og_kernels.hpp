@@ -478,13 +478,8 @@ __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16*
     // accumulator-layout role: channel li, pixel rows 8g + 4lh + rr
     float* const fw = (float*)scratch + (128 * lh + li);            // + (8g + rr) * 32
     const float* const fr = (const float*)scratch + rrow * 32 + rc4;  // + q * 256
-    __amdgpu_buffer_rsrc_t res_rs = out_rs, pool_rs = out_rs;
-    unsigned vres[4] = {0, 0, 0, 0}, vpool = 0;
-    if (RES) {
-        res_rs = og_rsrc(a.res + (long long)b * a.res_frame_stride, (unsigned)a.res_frame_stride * 4u);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) vres[g] = (tx0 + 4 * g + 2 * lh < a.W) ? (unsigned)((2 * lh * a.res_pix_stride + li) * 4) : OG_OOB;
-    }
+    __amdgpu_buffer_rsrc_t pool_rs = out_rs;
+    unsigned vpool = 0;
     const bool pool = (MODE == 0 && a.pool != nullptr);
     if (pool) {
         pool_rs = og_rsrc(a.pool + (long long)b * a.pool_frame_stride, (unsigned)a.pool_frame_stride * 4u);
@@ -525,10 +520,10 @@ __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16*
                 float v = (rr == 0) ? a01.x : (rr == 1) ? a01.y : (rr == 2) ? a23.x : a23.y;
                 if (ACT == 1) v = fmaxf(v, 0.f);
                 if (ACT == 2) v = v / (1.0f + expf(-v));
-                if (RES) {
-                    const unsigned so = (unsigned)((((y0 + (rr >> 1)) * OW + tx0 + 4 * g + (rr & 1)) * a.res_pix_stride + a.res_ch_off + cbase) * 4);
-                    const float r = __builtin_amdgcn_raw_buffer_load_b32(res_rs, (y0 + (rr >> 1) < a.H) ? vres[g] : OG_OOB, so, 0);
-                    v += r;
+                if (RES) {  // detector bottlenecks only: plain per-element loads
+                    const int y = y0 + (rr >> 1), x = tx0 + 4 * g + 2 * lh + (rr & 1);
+                    if (y < a.H && x < a.W)
+                        v += a.res[(long long)b * a.res_frame_stride + ((long long)y * OW + x) * a.res_pix_stride + a.res_ch_off + cbase + li];
                 }
                 fw[(8 * g + rr) * 32] = v;
                 vmaxs[g] = (rr == 0) ? v : fmaxf(vmaxs[g], v);

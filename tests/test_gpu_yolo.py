@@ -105,3 +105,15 @@ def test_gated_pipeline_end_to_end(det):
         b = td.detect(f)
         want = 0.0 if b is None else float(np.sum(masks[i][b[1]:b[3], b[0]:b[2]] > 0))
         assert wave[i] == want
+
+
+def test_large_batch_takes_the_occupancy_kernels_and_agrees_with_small_batches(det):
+    """At >= 3 workgroups per CU a 3x3 conv launch switches from the persistent kernel to the occupancy kernel
+    (lean epilogue: SiLU, residual, bounds-check clipping).  Same arithmetic order -> same predictions, frame by frame."""
+    _, d = det
+    f = frames(192, seed=11)
+    best_big, pred_big = d.detect_batch(f, 0.25, want_pred=True)
+    for lo in (0, 95, 190):
+        b, p = d.detect_batch(f[lo:lo + 2], 0.25, want_pred=True)
+        np.testing.assert_array_equal(pred_big[lo:lo + 2], p)
+        np.testing.assert_array_equal(best_big[lo:lo + 2], b)
