@@ -104,6 +104,8 @@ struct og_unet {
     int conv_impl = 2;   // 0 k_conv_mfma | 1 k_conv_mfma_p (persistent, pipelined) | 2 auto: k_conv_mfma_o (3 WG/CU, single halo
                          // buffer) for full launches, k_conv_mfma_p + split-K for launches that cannot fill the chip | 3 k_conv_mfma_o, 4 WG/CU
     int tps_nt1 = 3;     // taps per step for the 32-column kernel
+    int occ_min_pct = 100; // occupancy kernel when workgroups >= pct % of the CU count (0: one full round of 2-3 per CU);
+                           // measured 25..300 at 2..32 frames per launch: 100 is best or within 1 % everywhere
     int tps_nt2 = 1;     // taps per step for the 64-column kernel
     int prio_mode = 2;   // see ConvArgs::prio_mode (measured +1.2 % on the frame loop)
     // Two lanes: odd micro-batches of one call run on a twin handle (own stream, arena, graphs; SHARED weights), so
@@ -526,7 +528,8 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         // The occupancy variant needs at least one full round of workgroups (2/CU on 16x16 tiles, 3/CU on
         // 8x16); below that the persistent kernel (2/CU, balanced static schedule, split-K when the launch
         // cannot even fill a quarter of the chip) is faster.
-        const bool occ_fills = (a.n_spatial * nt >= h->n_cu * (big ? 2 : 3));
+        const bool occ_fills = h->occ_min_pct ? (a.n_spatial * nt * 100 >= h->n_cu * h->occ_min_pct)
+                                              : (a.n_spatial * nt >= h->n_cu * (big ? 2 : 3));
         if ((ks > 1 && a.head_w == nullptr) || (impl == 2 && !occ_fills)) {
             impl = 1;
             big = false;
@@ -1105,6 +1108,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     if (n == "conv_impl" && value >= 0 && value <= 3) slot = &h->conv_impl;
     else if (n == "tps_nt1" && (value == 1 || value == 3 || value == 9)) slot = &h->tps_nt1;
     else if (n == "tps_nt2" && (value == 1 || value == 3)) slot = &h->tps_nt2;
+    else if (n == "occ_min_pct" && value >= 0 && value <= 400) slot = &h->occ_min_pct;
     else if (n == "wg_per_cu" && value >= 1 && value <= 2) slot = &h->wg_per_cu;
     else if (n == "prio_mode" && value >= 0 && value <= 2) slot = &h->prio_mode;
     else if (n == "splitk" && (value == 0 || value == 1)) slot = &h->splitk;
