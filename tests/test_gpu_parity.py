@@ -421,3 +421,28 @@ def test_device_crop_letterbox_paste_equals_host_geometry(trained):
             want[y1:y2, x1:x2] = unletterbox(mk[0], pt, pl, ch, cw, crop.shape[0], crop.shape[1], interp=INTER_NEAREST)
         assert np.array_equal(dev[i], want), (i, b)
     assert np.array_equal(E.unet_on_crops(fr, boxes, m), dev)
+
+
+def test_occupancy_kernels_on_partial_tiles_large_batch():
+    """A batch large enough that every layer takes the occupancy kernel (buffer-addressed halo, bounds-check zero
+    padding and clipping) on shapes whose deeper levels do not tile evenly (80x48: 40x24, 20x12, 10x6 ...), against
+    (a) the persistent kernels on the same frames (split-K off: same summation order -> bit-identical) and
+    (b) the oracle on a few frames."""
+    from oracle import unet_oracle as O
+    feats = (32, 64, 128)
+    sd = synth.make_unet_state_dict(feats, seed=321, head_scale=2.0, head_bias=-0.5)
+    m = make_model(sd, feats)
+    m.set_option("splitk", 0)
+    B, H, W = 96, 80, 48
+    fr = synth.random_gray_frames(B, H, W, seed=17)
+    m.set_chunk(96)
+    masks, areas, logits = m.segment(fr, want_logits=True)
+    m.set_chunk(1)                      # one frame per chain: nothing fills the chip -> persistent kernels
+    masks1, areas1, logits1 = m.segment(fr[:6], want_logits=True)
+    assert np.array_equal(logits[:6], logits1) and np.array_equal(masks[:6], masks1) and np.array_equal(areas[:6], areas1)
+    ref_mask, ref_logits = O.segment_frames(sd, fr[:4], backend="torch")
+    scale = max(1.0, np.abs(ref_logits).max())
+    assert np.abs(logits[:4] - ref_logits).max() <= TOL * scale
+    diff = (masks[:4] > 0) != (ref_mask > 0)
+    assert np.all(np.abs(ref_logits[diff]) <= TOL * scale)
+    assert np.array_equal(areas, (masks > 0).reshape(B, -1).sum(1))

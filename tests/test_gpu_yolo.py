@@ -117,3 +117,10 @@ def test_large_batch_takes_the_occupancy_kernels_and_agrees_with_small_batches(d
         b, p = d.detect_batch(f[lo:lo + 2], 0.25, want_pred=True)
         np.testing.assert_array_equal(pred_big[lo:lo + 2], p)
         np.testing.assert_array_equal(best_big[lo:lo + 2], b)
+    # rectangular input whose deepest maps have an odd height (5 x 8): partial tiles and the half-row clipping
+    f = frames(160, 160, 256, seed=12)
+    best_big, pred_big = d.detect_batch(f, 0.25, want_pred=True)
+    for lo in (0, 77, 158):
+        b, p = d.detect_batch(f[lo:lo + 2], 0.25, want_pred=True)
+        np.testing.assert_array_equal(pred_big[lo:lo + 2], p)
+        np.testing.assert_array_equal(best_big[lo:lo + 2], b)
