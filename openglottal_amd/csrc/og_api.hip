@@ -435,6 +435,8 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     if ((rc = set_conv_p_attr<2, 1, 8, 1>())) return rc;
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                conv_o_lds<1, 0, 8>() + (12 * 20 + 352) * 4));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 2, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 2, 8>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 2, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 2, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 3, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 3, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 3, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 3, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 16>()));

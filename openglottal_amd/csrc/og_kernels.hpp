@@ -77,6 +77,11 @@ __device__ __forceinline__ void glds16b(unsigned voff, og_i32x4 rsrc, unsigned s
         : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_wave_base)
         : "memory");
 }
+// Compiler-only fence for LDS data exchanged inside ONE wave (the LDS itself keeps a wave's accesses in order).
+__device__ __forceinline__ void og_lds_order() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ float og_act(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
     if (act == 2) return v / (1.0f + expf(-v));  // SiLU = x * sigmoid(x)
@@ -140,6 +145,7 @@ struct ConvArgs {
 
 // MODE 0: 3x3 conv, pad 1, stride 1  (+ per-channel affine, ReLU, optional 2x2 max-pool)
 // MODE 1: 2x2 stride-2 transposed conv as one GEMM with N = 4*Cout (dy,dx,co), scattered store
+// MODE 2: 1x1 conv (detector): no halo border, one tap, plain epilogue
 // MODE 3 (k_conv_mfma_o only): 3x3 stride-2 pad-1 conv (YOLOv8 down-sampling Conv) as a 2x2 stride-1 conv over the
 //         space-to-depth view of the input; a.H, a.W are the OUTPUT size (input = 2H x 2W), a.n_chunks = 4 * Cin_p / 32
 // NT    : 32-column output sub-tiles per workgroup (Cout tile = 32*NT); waves are laid out (4/NT) x NT
@@ -377,6 +383,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16* a
             }
             vmaxs[g] = vmax;
         }
+        og_lds_order();  // float writes above, f32x4 reads below, same wave: keep hipcc from reordering them (TBAA)
         // full-resolution tile: 4 x (64 lanes x 16 B)
         const bool fuse_head = (MODE == 0 && NT == 1 && a.head_w != nullptr);
         const bool store_act = !fuse_head || a.head_store_act;
@@ -415,12 +422,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16* a
             // pooled tile: 8 windows x 32 channels = exactly one 16-B store per lane
 #pragma unroll
             for (int g = 0; g < 4; ++g) fs[1024 + (2 * g + lh) * 32 + li] = vmaxs[g];   // scratch bytes [4096, 5120)
+            og_lds_order();
             const f32x4 p4 = *(const f32x4*)(fs + 1024 + rrow * 32 + rc4);
             const int y = ty0 + 2 * ms, x = tx0 + 2 * rrow;
             if (y < a.H && x < a.W)
                 *(f32x4*)(a.pool + (long long)b * a.pool_frame_stride + ((long long)(y >> 1) * (a.W >> 1) + (x >> 1)) * a.pool_pix_stride +
                           a.pool_ch_off + cbase + rc4) = p4;
         }
+        og_lds_order();
     }
     if (MODE == 0 && NT == 1 && a.head_w != nullptr && a.head_area != nullptr) {
         // one plain store per wave into a per-(frame, tile, wave) slot; k_sum_counts adds them up per frame.
@@ -443,6 +452,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16* a
 //  * the fused head evaluates sigmoid / threshold / box test once per 32-pixel sub-tile (one pixel per lane) and
 //    counts with a ballot + scalar popcount instead of four 8-pixel rounds and a shuffle reduction.
 typedef unsigned og_u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t og_rsrc(const void* base, unsigned bytes) {
     const unsigned long long v = (unsigned long long)base;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -510,11 +520,8 @@ __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16*
         const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            // scalar fmas on purpose: with v_pk_fma_f32 here the ReLU layers stayed bit-exact but a few lanes of the
-            // ACT 0 (transposed conv) and ACT 2 (SiLU) outputs came out wrong on gfx950 (tools/dbg_layers.py); the
-            // packed form is kept only in the fused first layer, where the variant test pins it bit for bit
-            const f32x2 a01 = og_fma2s(f32x2{acc[m][4 * g], acc[m][4 * g + 1]}, sc2, sh2);
-            const f32x2 a23 = og_fma2s(f32x2{acc[m][4 * g + 2], acc[m][4 * g + 3]}, sc2, sh2);
+            const f32x2 a01 = og_fma2(f32x2{acc[m][4 * g], acc[m][4 * g + 1]}, sc2, sh2);
+            const f32x2 a23 = og_fma2(f32x2{acc[m][4 * g + 2], acc[m][4 * g + 3]}, sc2, sh2);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 float v = (rr == 0) ? a01.x : (rr == 1) ? a01.y : (rr == 2) ? a23.x : a23.y;
@@ -529,9 +536,13 @@ __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16*
                 vmaxs[g] = (rr == 0) ? v : fmaxf(vmaxs[g], v);
             }
         }
+        // The scratch is written as float and read back as f32x4 by the SAME wave (the LDS keeps a wave's accesses in
+        // order), but type-based alias analysis lets hipcc move such reads above the writes: fence the compiler.
+        og_lds_order();
         f32x4 v4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v4[q] = *(const f32x4*)(fr + q * 256);
+        og_lds_order();
         if (y0 < a.H) {
             const bool half = (y0 + 1 >= a.H);   // odd H (detector maps of 160-pixel inputs): only the first row exists
             if (store_act) {
@@ -577,7 +588,9 @@ __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16*
                 // pooled tile: 8 windows x 32 channels = exactly one 16-B store per lane
 #pragma unroll
                 for (int g = 0; g < 4; ++g) fw[1024 - 96 * lh + g * 64] = vmaxs[g];  // fs[1024 + (2g + lh) * 32 + li]
+                og_lds_order();
                 const f32x4 p4 = *(const f32x4*)(fr + 1024);
+                og_lds_order();
                 const int so = (((y0 >> 1) * (a.W >> 1) + (tx0 >> 1)) * a.pool_pix_stride + a.pool_ch_off + cbase) * 4;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(og_u32x4, p4), pool_rs, vpool, so, 0);
             }
