@@ -437,6 +437,8 @@ def test_occupancy_kernels_on_partial_tiles_large_batch():
     fr = synth.random_gray_frames(B, H, W, seed=17)
     m.set_chunk(96)
     masks, areas, logits = m.segment(fr, want_logits=True)
+    masks_again, areas_again, logits_again = m.segment(fr, want_logits=True)      # same launch twice: bit-identical
+    assert np.array_equal(logits, logits_again) and np.array_equal(masks, masks_again) and np.array_equal(areas, areas_again)
     m.set_chunk(1)                      # one frame per chain: nothing fills the chip -> persistent kernels
     masks1, areas1, logits1 = m.segment(fr[:6], want_logits=True)
     assert np.array_equal(logits[:6], logits1) and np.array_equal(masks[:6], masks1) and np.array_equal(areas[:6], areas1)
