@@ -104,6 +104,8 @@ struct og_unet {
     int conv_impl = 2;   // 0 k_conv_mfma | 1 k_conv_mfma_p (persistent, pipelined) | 2 auto: k_conv_mfma_o (3 WG/CU, single halo
                          // buffer) for full launches, k_conv_mfma_p + split-K for launches that cannot fill the chip | 3 k_conv_mfma_o, 4 WG/CU
     int tps_nt1 = 3;     // taps per step for the 32-column kernel
+    int splitk_occ = 1;  // split-K parts on the occupancy kernel (0: persistent kernel)
+    int splitk_slots = 2, splitk_div = 4;  // occupancy split-K: target workgroups per CU; split when the launch fills < 1/div of them
     int occ_min_pct = 100; // occupancy kernel when workgroups >= pct % of the CU count (0: one full round of 2-3 per CU);
                            // measured 25..300 at 2..32 frames per launch: 100 is best or within 1 % everywhere
     int tps_nt2 = 1;     // taps per step for the 64-column kernel
@@ -363,8 +365,8 @@ constexpr size_t kPartialBytes = 64u << 20;  // split-K workspace (only small la
 // Split-K factor for a launch of `n_items` tiles over `n_chunks` 32-channel chunks: only when the
 // launch would leave >= 3/4 of the workgroup slots empty (small-batch / latency mode), so that
 // throughput-mode results do not depend on the micro-batch size.
-inline int pick_ksplit(int n_items, int n_chunks, int slots, int ms, bool enable) {
-    if (!enable || n_chunks < 2 || n_items * 4 > slots) return 1;
+inline int pick_ksplit(int n_items, int n_chunks, int slots, int ms, bool enable, int fill_div = 4) {
+    if (!enable || n_chunks < 2 || n_items * fill_div > slots) return 1;
     int k = slots / n_items;
     if (k > n_chunks) k = n_chunks;
     const size_t per_item = (size_t)4 * ms * 16 * 64 * sizeof(float);
@@ -386,8 +388,13 @@ int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     static_assert(lds >= 4 * 5120, "the epilogue's per-wave scratch needs 20 KB");
     ConvArgs a = a_in;
     a.stamps = nullptr;  // the probe buffer is sized for the persistent kernel's grid; this kernel's timeline is tools/ubench/occ_timeline
-    hipLaunchKernelGGL((k_conv_mfma_o<NT, MODE, TH, OCC>), dim3(a.n_spatial * n_ntiles), dim3(256), lds, c.stream, a);
+    if (MODE != 0 && MODE != 1) a.ksplit = 1;
+    hipLaunchKernelGGL((k_conv_mfma_o<NT, MODE, TH, OCC>), dim3(a.n_spatial * n_ntiles * a.ksplit), dim3(256), lds, c.stream, a);
     HIPCHK(hipGetLastError());
+    if (a.ksplit > 1) {
+        hipLaunchKernelGGL((k_splitk_epilogue<NT, MODE, TH>), dim3(a.n_spatial * n_ntiles), dim3(256), 4 * 5120, c.stream, a);
+        HIPCHK(hipGetLastError());
+    }
     return OG_OK;
 }
 
@@ -525,19 +532,22 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     if (impl == 1 || impl == 2) {
         const int nt = (L.mode == 0) ? L.Cout_p / (32 * L.NT) : 4 * L.Cout_p / 64;
         const int tiles8 = B * a.tiles_x * ((in.H + 7) / 8);
-        const int ks = pick_ksplit(tiles8 * nt, a.n_chunks, h->n_cu * h->wg_per_cu, (L.NT == 2) ? 2 : 1,
-                                   h->splitk != 0 && h->d_partial != nullptr);
+        const bool sk_occ = (impl == 2 && h->splitk_occ);
+        const int ks = pick_ksplit(tiles8 * nt, a.n_chunks, h->n_cu * (sk_occ ? h->splitk_slots : h->wg_per_cu), (L.NT == 2) ? 2 : 1,
+                                   h->splitk != 0 && h->d_partial != nullptr, sk_occ ? h->splitk_div : 4);
         // The occupancy variant needs at least one full round of workgroups (2/CU on 16x16 tiles, 3/CU on
         // 8x16); below that the persistent kernel (2/CU, balanced static schedule, split-K when the launch
         // cannot even fill a quarter of the chip) is faster.
         const bool occ_fills = h->occ_min_pct ? (a.n_spatial * nt * 100 >= h->n_cu * h->occ_min_pct)
                                               : (a.n_spatial * nt >= h->n_cu * (big ? 2 : 3));
-        if ((ks > 1 && a.head_w == nullptr) || (impl == 2 && !occ_fills)) {
-            impl = 1;
+        const bool split = (ks > 1 && a.head_w == nullptr);  // the fused head lives in the conv epilogue: no split-K on that launch
+        if (split || (impl == 2 && !occ_fills)) {
+            // h->splitk_occ: the K parts run on the (leaner) occupancy kernel, one workgroup per part; else the persistent kernel
+            impl = (split && impl == 2 && h->splitk_occ) ? 4 : 1;
             big = false;
             a.tiles_y = (in.H + 7) / 8;
             a.n_spatial = tiles8;
-            a.ksplit = (a.head_w == nullptr) ? ks : 1;  // the fused head lives in the conv epilogue: no split-K on that launch
+            a.ksplit = split ? ks : 1;
         }
     }
     a.stamps = nullptr;
@@ -557,6 +567,9 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
             a.ksplit = 1;
             prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma_o<2,0,16>" : "k_conv_mfma_o<1,0,16>", fl);
             rc = (L.NT == 2) ? launch_conv_o<2, 0, 16, 2>(ctx, a, n_ntiles) : launch_conv_o<1, 0, 16, 2>(ctx, a, n_ntiles);
+        } else if (impl == 4) {
+            prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma_o<2,0,8>+splitK" : "k_conv_mfma_o<1,0,8>+splitK", fl);
+            rc = (L.NT == 2) ? launch_conv_o<2, 0, TH, 3>(ctx, a, n_ntiles) : launch_conv_o<1, 0, TH, 3>(ctx, a, n_ntiles);
         } else if (impl == 2 || impl == 3) {
             a.ksplit = 1;
             prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma_o<2,0,8>" : "k_conv_mfma_o<1,0,8>", fl);
@@ -610,6 +623,9 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     if (impl == 0) {
         prof_begin(h, L.name, "k_conv_mfma<2,1,8>", flt);
         rc = launch_conv_t<2, 1, TH>(h, a, 4 * L.Cout_p / 64);
+    } else if (impl == 4) {
+        prof_begin(h, L.name, "k_conv_mfma_o<2,1,8>+splitK", flt);
+        rc = launch_conv_o<2, 1, TH, 3>(ctx, a, 4 * L.Cout_p / 64);
     } else if (impl >= 2 && h->convt_occ) {
         a.ksplit = 1;
         prof_begin(h, L.name, "k_conv_mfma_o<2,1,8>", flt);
@@ -1110,6 +1126,9 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     if (n == "conv_impl" && value >= 0 && value <= 3) slot = &h->conv_impl;
     else if (n == "tps_nt1" && (value == 1 || value == 3 || value == 9)) slot = &h->tps_nt1;
     else if (n == "tps_nt2" && (value == 1 || value == 3)) slot = &h->tps_nt2;
+    else if (n == "splitk_occ" && (value == 0 || value == 1)) slot = &h->splitk_occ;
+    else if (n == "splitk_slots" && value >= 1 && value <= 4) slot = &h->splitk_slots;
+    else if (n == "splitk_div" && value >= 1 && value <= 8) slot = &h->splitk_div;
     else if (n == "occ_min_pct" && value >= 0 && value <= 400) slot = &h->occ_min_pct;
     else if (n == "wg_per_cu" && value >= 1 && value <= 2) slot = &h->wg_per_cu;
     else if (n == "prio_mode" && value >= 0 && value <= 2) slot = &h->prio_mode;

@@ -674,9 +674,14 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
         st[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_REG_XCC_ID
     }
 
-    // ---- tile decode (scalar) ----
-    const int n_tile = blockIdx.x / a.n_spatial;
-    int sp = blockIdx.x - n_tile * a.n_spatial;
+    // ---- tile decode (scalar); split-K (latency mode, MODE 0/1): workgroup = (tile, K part), K part = a chunk range ----
+    const int ks_n = (MODE == 0 || MODE == 1) ? a.ksplit : 1;
+    const int tile_id = (ks_n == 1) ? (int)blockIdx.x : (int)blockIdx.x / ks_n;
+    const int kpart = (ks_n == 1) ? 0 : (int)blockIdx.x - tile_id * ks_n;
+    const int c_lo = (ks_n == 1) ? 0 : (kpart * a.n_chunks) / ks_n;
+    const int c_hi = (ks_n == 1) ? a.n_chunks : ((kpart + 1) * a.n_chunks) / ks_n;
+    const int n_tile = tile_id / a.n_spatial;
+    int sp = tile_id - n_tile * a.n_spatial;
     const int tiles_per_frame = a.tiles_x * a.tiles_y;
     const int b = sp / tiles_per_frame;
     sp -= b * tiles_per_frame;
@@ -814,8 +819,8 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
         }
     } else {
         if (st != nullptr && tid == 0) st[6] = __builtin_amdgcn_s_memtime();
-        stage_halo(0, 0);
-        stage_w(0, 0);
+        stage_halo(0, c_lo);
+        stage_w((NSTG == 3) ? 0 : ((c_lo * TAPS) & 1), c_lo * TAPS);
     }
     og_wait_dma();
     if (st != nullptr && tid == 0) st[7] = __builtin_amdgcn_s_memtime();
@@ -823,8 +828,9 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     if (st != nullptr && tid == 0) st[1] = __builtin_amdgcn_s_memtime();
     if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(0);
 
-    int step = 0;
-    for (int c = 0; c < a.n_chunks; ++c) {
+    int step = c_lo * TAPS;                      // absolute (chunk, tap) index: also the weight block's index
+    const int step_end = (MODE == 3) ? total_steps : c_hi * TAPS;
+    for (int c = c_lo; c < c_hi; ++c) {
         const unsigned char* hb = halo0;
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
@@ -833,7 +839,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
                 if (((t >> 1) == 0 && (par & 2) == 0) || ((t & 1) == 0 && (par & 1) == 0)) continue;
             }
             const int stg = (NSTG == 3) ? t % 3 : (step & 1), stg_next = (NSTG == 3) ? (t + 1) % 3 : ((step + 1) & 1);
-            if (step + 1 < total_steps) stage_w(stg_next, step + 1);
+            if (step + 1 < step_end) stage_w(stg_next, step + 1);
 
             const unsigned char* wb = wbuf0 + stg * WBYTES;
             const int dy = (MODE == 0) ? t / 3 : (MODE == 3) ? (t >> 1) : 0;
@@ -855,7 +861,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
             __syncthreads();
             ++step;
         }
-        if (c + 1 < a.n_chunks) {  // every read of the halo buffer completed before the barrier above
+        if (c + 1 < c_hi) {  // every read of the halo buffer completed before the barrier above
             stage_halo(0, c + 1);
             og_wait_dma();
             __syncthreads();
@@ -865,7 +871,15 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     if (st != nullptr && tid == 0) st[2] = __builtin_amdgcn_s_memtime();
     if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(3);
     // ---- epilogue (all staging buffers are dead behind the last barrier: LDS is scratch now) ----
-    {
+    if (ks_n > 1) {
+        // split-K: raw accumulators, register order, lane-contiguous (256-B stores); k_splitk_epilogue sums the parts
+        // in split order and runs the epilogue
+        float* pw = a.partial + ((long long)blockIdx.x * 4 + wave) * (MS * 16 * 64) + lane;
+#pragma unroll
+        for (int m = 0; m < MS; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pw[(m * 16 + r) * 64] = acc[m][r];
+    } else {
         unsigned char* const scr = smem + wave * 5120;
         if (a.act == 1) conv_epilogue_b<NT, MODE, TH, 1, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
         else if (a.act == 2 && a.res != nullptr) conv_epilogue_b<NT, MODE, TH, 2, true>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
