@@ -105,6 +105,7 @@ struct og_unet {
                          // buffer) for full launches, k_conv_mfma_p + split-K for launches that cannot fill the chip | 3 k_conv_mfma_o, 4 WG/CU
     int tps_nt1 = 3;     // taps per step for the 32-column kernel
     int splitk_occ = 1;  // split-K parts on the occupancy kernel (0: persistent kernel)
+    int splitk_min_steps = 9;  // smallest K part of a split 3x3 conv, in (chunk, tap) steps (9 = one channel chunk)
     int splitk_slots = 2, splitk_div = 4;  // occupancy split-K: target workgroups per CU; split when the launch fills < 1/div of them
     int occ_min_pct = 100; // occupancy kernel when workgroups >= pct % of the CU count (0: one full round of 2-3 per CU);
                            // measured 25..300 at 2..32 frames per launch: 100 is best or within 1 % everywhere
@@ -533,7 +534,9 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         const int nt = (L.mode == 0) ? L.Cout_p / (32 * L.NT) : 4 * L.Cout_p / 64;
         const int tiles8 = B * a.tiles_x * ((in.H + 7) / 8);
         const bool sk_occ = (impl == 2 && h->splitk_occ);
-        const int ks = pick_ksplit(tiles8 * nt, a.n_chunks, h->n_cu * (sk_occ ? h->splitk_slots : h->wg_per_cu), (L.NT == 2) ? 2 : 1,
+        // occupancy split-K of a 3x3 conv: parts are ranges of (chunk, tap) steps, at least splitk_min_steps each
+        const int k_units = (sk_occ && L.mode == 0) ? (a.n_chunks * 9) / h->splitk_min_steps : a.n_chunks;
+        const int ks = pick_ksplit(tiles8 * nt, k_units, h->n_cu * (sk_occ ? h->splitk_slots : h->wg_per_cu), (L.NT == 2) ? 2 : 1,
                                    h->splitk != 0 && h->d_partial != nullptr, sk_occ ? h->splitk_div : 4);
         // The occupancy variant needs at least one full round of workgroups (2/CU on 16x16 tiles, 3/CU on
         // 8x16); below that the persistent kernel (2/CU, balanced static schedule, split-K when the launch
@@ -1128,6 +1131,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "tps_nt2" && (value == 1 || value == 3)) slot = &h->tps_nt2;
     else if (n == "splitk_occ" && (value == 0 || value == 1)) slot = &h->splitk_occ;
     else if (n == "splitk_slots" && value >= 1 && value <= 4) slot = &h->splitk_slots;
+    else if (n == "splitk_min_steps" && value >= 1 && value <= 9) slot = &h->splitk_min_steps;
     else if (n == "splitk_div" && value >= 1 && value <= 8) slot = &h->splitk_div;
     else if (n == "occ_min_pct" && value >= 0 && value <= 400) slot = &h->occ_min_pct;
     else if (n == "wg_per_cu" && value >= 1 && value <= 2) slot = &h->wg_per_cu;

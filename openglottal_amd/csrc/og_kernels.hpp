@@ -674,12 +674,16 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
         st[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_REG_XCC_ID
     }
 
-    // ---- tile decode (scalar); split-K (latency mode, MODE 0/1): workgroup = (tile, K part), K part = a chunk range ----
+    // ---- tile decode (scalar); split-K (latency mode, MODE 0/1): workgroup = (tile, K part), K part = a range of
+    //      (chunk, tap) steps, so that a 3x3 conv splits finer than its channel chunks ----
     const int ks_n = (MODE == 0 || MODE == 1) ? a.ksplit : 1;
     const int tile_id = (ks_n == 1) ? (int)blockIdx.x : (int)blockIdx.x / ks_n;
     const int kpart = (ks_n == 1) ? 0 : (int)blockIdx.x - tile_id * ks_n;
-    const int c_lo = (ks_n == 1) ? 0 : (kpart * a.n_chunks) / ks_n;
-    const int c_hi = (ks_n == 1) ? a.n_chunks : ((kpart + 1) * a.n_chunks) / ks_n;
+    constexpr int TAPS_ = (MODE == 0) ? 9 : 1;
+    const int s_lo = (ks_n == 1) ? 0 : (kpart * a.n_chunks * TAPS_) / ks_n;
+    const int s_hi = (ks_n == 1) ? a.n_chunks * TAPS_ : ((kpart + 1) * a.n_chunks * TAPS_) / ks_n;
+    const int c_lo = (ks_n == 1) ? 0 : s_lo / TAPS_;
+    const int c_hi = (ks_n == 1) ? a.n_chunks : (s_hi + TAPS_ - 1) / TAPS_;
     const int n_tile = tile_id / a.n_spatial;
     int sp = tile_id - n_tile * a.n_spatial;
     const int tiles_per_frame = a.tiles_x * a.tiles_y;
@@ -820,7 +824,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     } else {
         if (st != nullptr && tid == 0) st[6] = __builtin_amdgcn_s_memtime();
         stage_halo(0, c_lo);
-        stage_w((NSTG == 3) ? 0 : ((c_lo * TAPS) & 1), c_lo * TAPS);
+        stage_w((NSTG == 3) ? s_lo % 3 : (s_lo & 1), s_lo);
     }
     og_wait_dma();
     if (st != nullptr && tid == 0) st[7] = __builtin_amdgcn_s_memtime();
@@ -828,12 +832,13 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     if (st != nullptr && tid == 0) st[1] = __builtin_amdgcn_s_memtime();
     if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(0);
 
-    int step = c_lo * TAPS;                      // absolute (chunk, tap) index: also the weight block's index
-    const int step_end = (MODE == 3) ? total_steps : c_hi * TAPS;
+    int step = s_lo;                             // absolute (chunk, tap) index: also the weight block's index
+    const int step_end = (MODE == 3) ? total_steps : s_hi;
     for (int c = c_lo; c < c_hi; ++c) {
         const unsigned char* hb = halo0;
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
+            if ((MODE == 0 || MODE == 1) && ks_n > 1 && (c * TAPS + t < s_lo || c * TAPS + t >= s_hi)) continue;  // another K part's step
             if (MODE == 3) {  // tap (ty,tx) of the 2x2 kernel meets parity (py,px): zero unless (ty==1 || py==1) and (tx==1 || px==1)
                 const int par = c / cpc;
                 if (((t >> 1) == 0 && (par & 2) == 0) || ((t & 1) == 0 && (par & 1) == 0)) continue;
