@@ -390,7 +390,11 @@ int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     ConvArgs a = a_in;
     a.stamps = nullptr;  // the probe buffer is sized for the persistent kernel's grid; this kernel's timeline is tools/ubench/occ_timeline
     if (MODE != 0 && MODE != 1) a.ksplit = 1;
-    hipLaunchKernelGGL((k_conv_mfma_o<NT, MODE, TH, OCC>), dim3(a.n_spatial * n_ntiles * a.ksplit), dim3(256), lds, c.stream, a);
+    const int frames = a.n_spatial / (a.tiles_x * a.tiles_y);
+    a.zdiv = n_ntiles * a.ksplit;
+    a.zrcp = 1.0f / (float)a.zdiv;
+    if ((long long)frames * a.zdiv > 65535) return fail(OG_EINVAL, "micro-batch too large for one launch (grid.z): lower the chunk size");
+    hipLaunchKernelGGL((k_conv_mfma_o<NT, MODE, TH, OCC>), dim3(a.tiles_x, a.tiles_y, frames * a.zdiv), dim3(256), lds, c.stream, a);
     HIPCHK(hipGetLastError());
     if (a.ksplit > 1) {
         hipLaunchKernelGGL((k_splitk_epilogue<NT, MODE, TH>), dim3(a.n_spatial * n_ntiles), dim3(256), 4 * 5120, c.stream, a);
@@ -705,7 +709,9 @@ int enqueue_first_fused(og_unet* h, const uint8_t* gray, int B, int H, int W) {
     constexpr int lds = conv_o_lds<1, 0, 8>() + (12 * 20 + 352) * 4;
     prof_begin(h, "downs.0 (first + second conv fused)", "k_conv_mfma_o<1,0,8,FIRST>",
                2.0 * B * H * W * 9.0 * (1.0 * h->features[0] + (double)h->features[0] * h->features[0]));
-    hipLaunchKernelGGL((k_conv_mfma_o<1, 0, 8, 3, true>), dim3(a.n_spatial), dim3(256), lds, h->stream, a);
+    a.zdiv = 1;
+    a.zrcp = 1.0f;
+    hipLaunchKernelGGL((k_conv_mfma_o<1, 0, 8, 3, true>), dim3(a.tiles_x, a.tiles_y, B), dim3(256), lds, h->stream, a);
     prof_end(h);
     HIPCHK(hipGetLastError());
     return OG_OK;

@@ -135,6 +135,8 @@ struct ConvArgs {
     uint8_t* head_mask;
     int32_t* head_area;
     int head_store_act;     // also store the activation tensor (parity/debug taps)
+    int zdiv;               // k_conv_mfma_o's grid.z = frame * zdiv + (column tile * ksplit + K part); zrcp = 1 / zdiv
+    float zrcp;
     int ksplit;             // >1: split-K.  Item = (tile, K-range); raw accumulators go to `partial`, and
     float* partial;         // k_splitk_epilogue sums them in split order and runs the epilogue (small-batch latency mode)
     int prio_mode;          // 0 off; 1/2: alternate s_setprio per unit, role = upper half of the grid / odd block
@@ -667,31 +669,32 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     // set-up, the DMA issue and the epilogue are served first; the main loops only need a slot every 64 cycles.
     if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(3);
     // diagnostic timeline (tools/ubench/occ_timeline.hip only; nullptr on every product path)
-    unsigned long long* const st = a.stamps ? a.stamps + 8ull * blockIdx.x : nullptr;
+    unsigned long long* const st = a.stamps ? a.stamps + 8ull * (((unsigned long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) : nullptr;
     if (st != nullptr && tid == 0) {
         st[0] = __builtin_amdgcn_s_memtime();
         st[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID: wave slot, SIMD, CU, SE
         st[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_REG_XCC_ID
     }
 
-    // ---- tile decode (scalar); split-K (latency mode, MODE 0/1): workgroup = (tile, K part), K part = a range of
-    //      (chunk, tap) steps, so that a 3x3 conv splits finer than its channel chunks ----
+    // ---- tile decode (scalar).  3-D grid (tile column, tile row, frame x column tile x K part): no integer division
+    //      on the way to the first DMA (each one is ~20 vector-ALU instructions, paid at the contended issue rate).
+    //      split-K (latency mode, MODE 0/1): K part = a range of (chunk, tap) steps ----
     const int ks_n = (MODE == 0 || MODE == 1) ? a.ksplit : 1;
-    const int tile_id = (ks_n == 1) ? (int)blockIdx.x : (int)blockIdx.x / ks_n;
-    const int kpart = (ks_n == 1) ? 0 : (int)blockIdx.x - tile_id * ks_n;
+    const int bz = (int)blockIdx.z;
+    const int b = (a.zdiv == 1) ? bz : (int)(((float)bz + 0.5f) * a.zrcp);   // zdiv = column tiles x K parts; exact for bz < 2^16
+    const int zr = bz - b * a.zdiv;
+    const int n_tile = (ks_n == 1) ? zr : zr / ks_n;
+    const int kpart = (ks_n == 1) ? 0 : zr - n_tile * ks_n;
     constexpr int TAPS_ = (MODE == 0) ? 9 : 1;
     const int s_lo = (ks_n == 1) ? 0 : (kpart * a.n_chunks * TAPS_) / ks_n;
     const int s_hi = (ks_n == 1) ? a.n_chunks * TAPS_ : ((kpart + 1) * a.n_chunks * TAPS_) / ks_n;
     const int c_lo = (ks_n == 1) ? 0 : s_lo / TAPS_;
     const int c_hi = (ks_n == 1) ? a.n_chunks : (s_hi + TAPS_ - 1) / TAPS_;
-    const int n_tile = tile_id / a.n_spatial;
-    int sp = tile_id - n_tile * a.n_spatial;
-    const int tiles_per_frame = a.tiles_x * a.tiles_y;
-    const int b = sp / tiles_per_frame;
-    sp -= b * tiles_per_frame;
-    const int tyi = sp / a.tiles_x;
-    const int ty0 = tyi * TH;
-    const int tx0 = (sp - tyi * a.tiles_x) * TW;
+    const int ty0 = (int)blockIdx.y * TH;
+    const int tx0 = (int)blockIdx.x * TW;
+    // linear ids (split-K partial buffer, diagnostic stamps): as k_splitk_epilogue decodes them
+    const int tile_id = n_tile * a.n_spatial + (b * a.tiles_y + (int)blockIdx.y) * a.tiles_x + (int)blockIdx.x;
+    const int item_id = tile_id * ks_n + kpart;
 
     // this frame's input as a raw buffer: offsets past num_records read as zeros (= the conv's zero padding)
     const og_i32x4 in_rsrc = og_make_rsrc(a.in + (long long)b * a.in_frame_stride + a.in_ch_off,
@@ -744,6 +747,13 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < NT; ++i) glds16b(woff, w_rsrc, (unsigned)step * WBYTES + i * 4096, base + i * 4096);
     };
+
+    // first halo and weights are on their way before the rest of the set-up (which then hides their latency)
+    if (!FIRST) {
+        if (st != nullptr && tid == 0) st[6] = __builtin_amdgcn_s_memtime();
+        stage_halo(0, c_lo);
+        stage_w((NSTG == 3) ? s_lo % 3 : (s_lo & 1), s_lo);
+    }
 
     // ---- fragment addressing ----
     // A rows: i -> 2x2-window-major pixel order, so that the 4 accumulator registers
@@ -821,10 +831,6 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
                 *(f32x4*)(halo0 + q * 16) = o;
             }
         }
-    } else {
-        if (st != nullptr && tid == 0) st[6] = __builtin_amdgcn_s_memtime();
-        stage_halo(0, c_lo);
-        stage_w((NSTG == 3) ? s_lo % 3 : (s_lo & 1), s_lo);
     }
     og_wait_dma();
     if (st != nullptr && tid == 0) st[7] = __builtin_amdgcn_s_memtime();
@@ -879,7 +885,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     if (ks_n > 1) {
         // split-K: raw accumulators, register order, lane-contiguous (256-B stores); k_splitk_epilogue sums the parts
         // in split order and runs the epilogue
-        float* pw = a.partial + ((long long)blockIdx.x * 4 + wave) * (MS * 16 * 64) + lane;
+        float* pw = a.partial + ((long long)item_id * 4 + wave) * (MS * 16 * 64) + lane;
 #pragma unroll
         for (int m = 0; m < MS; ++m)
 #pragma unroll

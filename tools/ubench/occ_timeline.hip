@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
     a.H = HW; a.W = HW; a.tiles_x = HW / 16; a.tiles_y = HW / TH; a.n_spatial = B * a.tiles_x * a.tiles_y;
     a.wpk = dw; a.scale = dsc; a.shift = dsh; a.aff_mod = Cout;
     a.out = dout; a.out_frame_stride = (long long)HW * HW * Cout; a.out_pix_stride = Cout;
-    a.zero_page = dz; a.act = 1; a.ksplit = 1;
+    a.zero_page = dz; a.act = 1; a.ksplit = 1; a.zdiv = 1; a.zrcp = 1.0f;
     a.prio_mode = (argc > 6) ? atoi(argv[6]) : 0;
     const int grid = a.n_spatial;
     CK(hipMalloc(&dst, (size_t)grid * 64));
@@ -55,15 +55,15 @@ int main(int argc, char** argv) {
         if (var == "n1") {
             const int lds = 18 * 10 * 128 + 3 * 32 * 128;
             CK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            hipLaunchKernelGGL((k_conv_mfma_o<1, 0, 8, 3>), dim3(grid), dim3(256), lds, 0, a);
+            hipLaunchKernelGGL((k_conv_mfma_o<1, 0, 8, 3>), dim3(a.tiles_x, a.tiles_y, B), dim3(256), lds, 0, a);
         } else if (var == "n2t8") {
             const int lds = 18 * 10 * 128 + 3 * 64 * 128;
             CK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            hipLaunchKernelGGL((k_conv_mfma_o<2, 0, 8, 3>), dim3(grid), dim3(256), lds, 0, a);
+            hipLaunchKernelGGL((k_conv_mfma_o<2, 0, 8, 3>), dim3(a.tiles_x, a.tiles_y, B), dim3(256), lds, 0, a);
         } else {
             const int lds = 18 * 18 * 128 + 3 * 64 * 128;
             CK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            hipLaunchKernelGGL((k_conv_mfma_o<2, 0, 16, 2>), dim3(grid), dim3(256), lds, 0, a);
+            hipLaunchKernelGGL((k_conv_mfma_o<2, 0, 16, 2>), dim3(a.tiles_x, a.tiles_y, B), dim3(256), lds, 0, a);
         }
         CK(hipGetLastError());
         CK(hipEventRecord(e1));
