@@ -88,6 +88,9 @@ __device__ __forceinline__ float og_act(float v, int act) {
     return v;
 }
 __device__ __forceinline__ void og_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// 16-byte LDS read from an absolute LDS byte address (no symbol-relative add: hipcc materialises `smem + x` as
+// "0 + x" per access once the control flow keeps it from hoisting that add)
+__device__ __forceinline__ f32x4 og_lds_read16(unsigned addr) { return *(const OG_LDS_AS f32x4*)(unsigned long long)addr; }
 __device__ __forceinline__ unsigned og_lds_addr(const void* p) {
     return (unsigned)(size_t)((OG_LDS_AS const unsigned char*)p);
 }
@@ -773,7 +776,16 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
         const int px = px0 + dx;
         const unsigned o = (unsigned)((pyl * HW_ + px) * 128 + ((lh ^ og_halo_swz(pyl, px)) << 4) + wm * (MS * 2 * HW_ * 128));
 #pragma unroll
-        for (int pat = 0; pat < 4; ++pat) abase[dx][pat] = o ^ (unsigned)(pat << 5);
+        for (int pat = 0; pat < 4; ++pat) {
+            abase[dx][pat] = lds0 + (o ^ (unsigned)(pat << 5));   // absolute LDS address
+            asm volatile("" : "+v"(abase[dx][pat]));              // opaque: or hipcc re-adds the (link-time 0) smem base per read
+        }
+    }
+    unsigned bbase[4];   // B fragments: stage 0 of the weight ring, k-group j
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        bbase[jj] = lds0 + HALO_BYTES + (unsigned)(boff ^ (jj << 5));
+        asm volatile("" : "+v"(bbase[jj]));
     }
 
     // this lane's output channel: folded BN scale / shift, loaded now so that the epilogue does not wait for them
@@ -841,7 +853,6 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     int step = s_lo;                             // absolute (chunk, tap) index: also the weight block's index
     const int step_end = (MODE == 3) ? total_steps : s_hi;
     for (int c = c_lo; c < c_hi; ++c) {
-        const unsigned char* hb = halo0;
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             if ((MODE == 0 || MODE == 1) && ks_n > 1 && (c * TAPS + t < s_lo || c * TAPS + t >= s_hi)) continue;  // another K part's step
@@ -852,16 +863,16 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
             const int stg = (NSTG == 3) ? t % 3 : (step & 1), stg_next = (NSTG == 3) ? (t + 1) % 3 : ((step + 1) & 1);
             if (step + 1 < step_end) stage_w(stg_next, step + 1);
 
-            const unsigned char* wb = wbuf0 + stg * WBYTES;
+            const unsigned wb = (unsigned)stg * WBYTES;
             const int dy = (MODE == 0) ? t / 3 : (MODE == 3) ? (t >> 1) : 0;
             const int dx = (MODE == 0) ? t % 3 : (MODE == 3) ? (t & 1) : 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // slot = (2j + lh) ^ swz  ==  ((lh ^ swz) << 4) ^ (j << 5) in bytes
-                const f32x4 bv = *(const f32x4*)(wb + (boff ^ (j << 5)));
+                const f32x4 bv = og_lds_read16(bbase[j] + wb);
 #pragma unroll
                 for (int m = 0; m < MS; ++m) {
-                    const f32x4 av = *(const f32x4*)(hb + abase[dx][j ^ ((dy & 1) << 1)] + (dy + 2 * m) * (HW_ * 128));
+                    const f32x4 av = og_lds_read16(abase[dx][j ^ ((dy & 1) << 1)] + (unsigned)((dy + 2 * m) * (HW_ * 128)));
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[m], 0, 0, 0);
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[m], 0, 0, 0);
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[m], 0, 0, 0);
