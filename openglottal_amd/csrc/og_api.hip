@@ -132,6 +132,8 @@ struct og_unet {
     int tile_h = 0;      // 0 auto (16x16 tiles for 64-channel-tile layers at <= 64x64 pixels, else 8x16) | 8 | 16
     int splitk = 1;      // allow split-K on launches that would fill < 1/4 of the chip (latency mode)
     float* d_partial = nullptr;
+    int* d_tile_counter = nullptr;   // split-K arrival counters (fused reduce), zero between launches
+    int splitk_fused = 1;            // last-arriving K part reduces + runs the epilogue (0: separate k_splitk_epilogue launch)
     int32_t* d_counts = nullptr;  // fused head: per-(frame, tile, wave) foreground counts of the current chunk
     size_t counts_cap = 0;
     int wg_per_cu = 2;   // persistent grid = wg_per_cu * CUs (capped by the item count)
@@ -394,9 +396,10 @@ int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     a.zdiv = n_ntiles * a.ksplit;
     a.zrcp = 1.0f / (float)a.zdiv;
     if ((long long)frames * a.zdiv > 65535) return fail(OG_EINVAL, "micro-batch too large for one launch (grid.z): lower the chunk size");
+    if (a.ksplit == 1 || a.n_spatial * n_ntiles > 4096) a.tile_counter = nullptr;
     hipLaunchKernelGGL((k_conv_mfma_o<NT, MODE, TH, OCC>), dim3(a.tiles_x, a.tiles_y, frames * a.zdiv), dim3(256), lds, c.stream, a);
     HIPCHK(hipGetLastError());
-    if (a.ksplit > 1) {
+    if (a.ksplit > 1 && a.tile_counter == nullptr) {
         hipLaunchKernelGGL((k_splitk_epilogue<NT, MODE, TH>), dim3(a.n_spatial * n_ntiles), dim3(256), 4 * 5120, c.stream, a);
         HIPCHK(hipGetLastError());
     }
@@ -533,6 +536,7 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     }
     a.ksplit = 1;
     a.partial = h->d_partial;
+    a.tile_counter = (h->splitk_fused && h->d_tile_counter) ? h->d_tile_counter : nullptr;
     int impl = h->conv_impl;
     if (impl == 1 || impl == 2) {
         const int nt = (L.mode == 0) ? L.Cout_p / (32 * L.NT) : 4 * L.Cout_p / 64;
@@ -970,6 +974,7 @@ void og_unet_destroy(og_unet* h) {
     if (h->stage) (void)hipFree(h->stage);
     if (h->d_stamps) (void)hipFree(h->d_stamps);
     if (h->d_partial) (void)hipFree(h->d_partial);
+    if (h->d_tile_counter) (void)hipFree(h->d_tile_counter);
     if (h->d_counts) (void)hipFree(h->d_counts);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1029,6 +1034,8 @@ int og_unet_finalize(og_unet* h) {
     HIPCHK(hipMalloc((void**)&h->d_zero, 4096));
     HIPCHK(hipMemset(h->d_zero, 0, 4096));
     HIPCHK(hipMalloc((void**)&h->d_partial, kPartialBytes));
+    HIPCHK(hipMalloc((void**)&h->d_tile_counter, 4096 * sizeof(int)));
+    HIPCHK(hipMemset(h->d_tile_counter, 0, 4096 * sizeof(int)));
 
     const int L = h->L;
     int rc;
@@ -1108,6 +1115,8 @@ int og_unet_finalize(og_unet* h) {
         HIPCHK(hipEventCreate(&t->ev0));
         HIPCHK(hipEventCreate(&t->ev1));
         HIPCHK(hipMalloc((void**)&t->d_partial, kPartialBytes));
+        HIPCHK(hipMalloc((void**)&t->d_tile_counter, 4096 * sizeof(int)));
+        HIPCHK(hipMemset(t->d_tile_counter, 0, 4096 * sizeof(int)));
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     }
@@ -1136,6 +1145,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "tps_nt1" && (value == 1 || value == 3 || value == 9)) slot = &h->tps_nt1;
     else if (n == "tps_nt2" && (value == 1 || value == 3)) slot = &h->tps_nt2;
     else if (n == "splitk_occ" && (value == 0 || value == 1)) slot = &h->splitk_occ;
+    else if (n == "splitk_fused" && (value == 0 || value == 1)) slot = &h->splitk_fused;
     else if (n == "splitk_slots" && value >= 1 && value <= 4) slot = &h->splitk_slots;
     else if (n == "splitk_min_steps" && value >= 1 && value <= 9) slot = &h->splitk_min_steps;
     else if (n == "splitk_div" && value >= 1 && value <= 8) slot = &h->splitk_div;

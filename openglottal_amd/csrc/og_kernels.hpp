@@ -142,6 +142,7 @@ struct ConvArgs {
     float zrcp;
     int ksplit;             // >1: split-K.  Item = (tile, K-range); raw accumulators go to `partial`, and
     float* partial;         // k_splitk_epilogue sums them in split order and runs the epilogue (small-batch latency mode)
+    int* tile_counter;      // k_conv_mfma_o split-K, fused reduce: arrivals per tile (zero between launches); nullptr = separate epilogue kernel
     int prio_mode;          // 0 off; 1/2: alternate s_setprio per unit, role = upper half of the grid / odd block
     unsigned long long* stamps;  // diagnostic only (nullptr in production): per workgroup
                                  // k_conv_mfma_p: 4 x u64 {s_memtime, s_memrealtime} at entry and exit -> in-kernel clock
@@ -897,10 +898,46 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
         // split-K: raw accumulators, register order, lane-contiguous (256-B stores); k_splitk_epilogue sums the parts
         // in split order and runs the epilogue
         float* pw = a.partial + ((long long)item_id * 4 + wave) * (MS * 16 * 64) + lane;
+        if (a.tile_counter == nullptr) {
 #pragma unroll
-        for (int m = 0; m < MS; ++m)
+            for (int m = 0; m < MS; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pw[(m * 16 + r) * 64] = acc[m][r];
+                for (int r = 0; r < 16; ++r) pw[(m * 16 + r) * 64] = acc[m][r];
+        } else {
+            // device-scope (write-through) stores: visible to the other XCDs once acknowledged, without flushing an L2
+#pragma unroll
+            for (int m = 0; m < MS; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) __hip_atomic_store(pw + (m * 16 + r) * 64, acc[m][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (a.tile_counter != nullptr) {
+            // Fused reduce: the LAST part of a tile to arrive sums all parts in split order (its own from memory too, so
+            // the result does not depend on who is last) and runs the epilogue -- one launch less per split layer.
+            // Device-scope release/acquire around the arrival counter: the parts come from other XCDs' L2s.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part is written through
+            __syncthreads();
+            int* const flag = (int*)smem;
+            if (tid == 0) *flag = (atomicAdd(a.tile_counter + tile_id, 1) == ks_n - 1) ? 1 : 0;
+            __syncthreads();
+            if (*(volatile int*)flag) {
+#pragma unroll
+                for (int m = 0; m < MS; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+                for (int sp_ = 0; sp_ < ks_n; ++sp_) {
+                    const float* pr = a.partial + (((long long)tile_id * ks_n + sp_) * 4 + wave) * (MS * 16 * 64) + lane;
+#pragma unroll
+                    for (int m = 0; m < MS; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[m][r] += __hip_atomic_load(pr + (m * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();   // the flag word is part of wave 0's scratch
+                unsigned char* const scr = smem + wave * 5120;
+                if (a.act == 1) conv_epilogue_b<NT, MODE, TH, 1, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+                else conv_epilogue_b<NT, MODE, TH, 0, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+                if (tid == 0) a.tile_counter[tile_id] = 0;   // ready for the next launch on this stream
+            }
+        }
     } else {
         unsigned char* const scr = smem + wave * 5120;
         if (a.act == 1) conv_epilogue_b<NT, MODE, TH, 1, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);

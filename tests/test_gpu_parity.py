@@ -199,6 +199,16 @@ def test_split_k_latency_mode(trained, full):
     m.set_chunk(32)
     assert not np.array_equal(l0, l1)                                                 # the split path really ran
     assert np.abs(l0 - l1).max() <= TOL
+    # fused reduce (last-arriving K part sums all parts in split order) == separate reduce kernel, bit for bit, every time
+    mf.set_chunk(1)
+    mf.set_option("splitk_fused", 0)
+    _, a_sep, l_sep = mf.segment(framesf, want_mask=False, want_logits=True)
+    mf.set_option("splitk_fused", 1)
+    for _ in range(3):
+        _, a_fu, l_fu = mf.segment(framesf, want_mask=False, want_logits=True)
+        assert np.array_equal(l_fu, l_sep) and np.array_equal(a_fu, a_sep)
+    assert np.array_equal(l_sep, l1)
+    mf.set_chunk(32)
     assert np.abs(l1.reshape(8, -1)[:, gf["sample_idx"]] - gf["logits_samples"]).max() <= TOL
     assert np.all(np.abs(a0.astype(int) - a1.astype(int)) <= ((l0 > 0) != (l1 > 0)).reshape(8, -1).sum(1))
 
