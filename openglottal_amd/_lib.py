@@ -84,6 +84,13 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or openglottal_amd/csrc/build.sh.  There is no CPU fallback."
             )
+        # PyTorch-ROCm bundles its own HIP/HSA runtime.  If our library (linked against the system ROCm) initialises HIP
+        # first, torch.cuda later reports "No HIP GPUs are available"; loaded in the other order, both share torch's copy.
+        # So pull torch in first whenever it is installed (the reference depends on it anyway).
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         try:
             l = C.CDLL(LIB_PATH)
         except OSError as e:  # missing libamdhip64 etc.

@@ -124,3 +124,19 @@ def test_large_batch_takes_the_occupancy_kernels_and_agrees_with_small_batches(d
         b, p = d.detect_batch(f[lo:lo + 2], 0.25, want_pred=True)
         np.testing.assert_array_equal(pred_big[lo:lo + 2], p)
         np.testing.assert_array_equal(best_big[lo:lo + 2], b)
+
+
+def test_device_entry_point_accepts_any_batch(det):
+    """og_yolo_detect_u8_dev chains at most 512 frames per launch internally; 600 frames in one call == per-chunk calls."""
+    import torch
+    from openglottal_amd._lib import check, lib, ptr
+    _, d = det
+    f = torch.from_numpy(frames(600, seed=21)).cuda()
+    best = torch.empty((600, 5), dtype=torch.float32, device="cuda")
+    check(lib().og_yolo_detect_u8_dev(d._h, ptr(f), 600, 256, 256, 0.25, ptr(best), None), "detect")
+    check(lib().og_yolo_sync(d._h), "sync")
+    ref = d.detect_batch(f[:8].cpu().numpy(), 0.25)
+    ref_tail = d.detect_batch(f[592:].cpu().numpy(), 0.25)
+    got = best.cpu().numpy()
+    np.testing.assert_array_equal(got[:8], ref)
+    np.testing.assert_array_equal(got[592:], ref_tail)
