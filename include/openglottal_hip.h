@@ -122,7 +122,7 @@ int og_unet_set_graphs(og_unet* h, int enable);
  * "splitk_occ" 0|1 (K parts of a split launch on the occupancy kernel; 0: persistent kernel), "splitk_slots" 1..4 and "splitk_div" 1..8
  * (its target workgroups per CU / split when the launch fills less than 1/div of them),
  * "occ_min_pct" 0..400 (occupancy kernel when a launch has at least that many workgroups per 100 CUs), "convt_occ" 0|1, "fuse_first" 0|1 (first layer computed inside downs.0's second conv), "fuse_head" 0|1 (head +
- * threshold + area inside the last conv's epilogue), "keep_taps" 0|1, "dual" 0|1 (odd micro-batches on a second stream/arena so that launch tails overlap), and
+ * threshold + area inside the last conv's epilogue), "keep_taps" 0|1, "dual" 0|1 (micro-batches of one call alternate over extra lanes = streams/arenas, so that launch tails overlap) with "lanes" 0..3 (0 = 3 lanes up to 16 frames per launch, else 2), and
  * "splitk" 0|1 (1 = launches that would fill < 1/4 of the chip split K across workgroups; sums
  * are taken in a fixed order, so results are deterministic but differ in the last bits from the
  * unsplit order). */

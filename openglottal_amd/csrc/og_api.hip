@@ -114,6 +114,7 @@ struct og_unet {
     // Two lanes: odd micro-batches of one call run on a twin handle (own stream, arena, graphs; SHARED weights), so
     // the launch tails of one chain are filled by the other chain's kernels (+2-4 % measured, tools/two_streams.py).
     og_unet* twin = nullptr;
+    int n_lanes = 0;   // lanes used per call when "dual" is on: 1..kMaxLanes, 0 = by micro-batch size
     bool is_twin = false;
     int dual = 1;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -363,6 +364,7 @@ struct LaunchCtx {
     int wg_per_cu;
 };
 
+constexpr int kMaxLanes = 3;   // a fourth lane measured slower than three at every micro-batch size
 constexpr size_t kPartialBytes = 64u << 20;  // split-K workspace (only small launches ever use it)
 
 // Split-K factor for a launch of `n_items` tiles over `n_chunks` 32-channel chunks: only when the
@@ -1090,7 +1092,10 @@ int og_unet_finalize(og_unet* h) {
     }
     h->host.clear();
     h->finalized = true;
-    {   // twin lane: same weights (pointers shared), own stream / events / split-K workspace; arena on demand
+    // extra lanes: same weights (pointers shared), own stream / events / split-K workspace; arena on demand.
+    // h -> twin -> twin's twin: micro-batch k of a call runs on lane k % n_lanes.
+    og_unet* prev = h;
+    for (int lane = 1; lane < kMaxLanes; ++lane) {
         og_unet* t = new og_unet();
         t->is_twin = true;
         t->features = h->features;
@@ -1110,30 +1115,32 @@ int og_unet_finalize(og_unet* h) {
         t->head_bias = h->head_bias;
         t->d_zero = h->d_zero;
         t->n_cu = h->n_cu;
-        h->twin = t;
+        prev->twin = t;
+        prev = t;
         HIPCHK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreate(&t->ev0));
         HIPCHK(hipEventCreate(&t->ev1));
         HIPCHK(hipMalloc((void**)&t->d_partial, kPartialBytes));
         HIPCHK(hipMalloc((void**)&t->d_tile_counter, 4096 * sizeof(int)));
         HIPCHK(hipMemset(t->d_tile_counter, 0, 4096 * sizeof(int)));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
     }
+    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     return OG_OK;
 }
 
 int og_unet_set_chunk(og_unet* h, int n) {
     if (!h || n < 1 || n > 4096) return fail(OG_EINVAL, "chunk must be in 1..4096");
     h->chunk = n;
-    if (h->twin) h->twin->chunk = n;
+    for (og_unet* t = h->twin; t; t = t->twin) t->chunk = n;
     return OG_OK;
 }
 
 int og_unet_set_graphs(og_unet* h, int enable) {
     if (!h) return fail(OG_EINVAL, "null handle");
     h->use_graphs = enable ? 1 : 0;
-    if (h->twin) h->twin->use_graphs = h->use_graphs;
+    for (og_unet* t = h->twin; t; t = t->twin) t->use_graphs = h->use_graphs;
     return OG_OK;
 }
 
@@ -1159,6 +1166,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "fuse_first" && (value == 0 || value == 1)) slot = &h->fuse_first;
     else if (n == "keep_taps" && (value == 0 || value == 1)) slot = &h->keep_taps;
     else if (n == "dual" && (value == 0 || value == 1)) slot = &h->dual;
+    else if (n == "lanes" && value >= 0 && value <= kMaxLanes) slot = &h->n_lanes;
     if (!slot) return fail(OG_EINVAL, "unknown option or bad value: " + n);
     if (*slot != value) {
         if (h->stream) HIPCHK(hipStreamSynchronize(h->stream));
@@ -1201,23 +1209,27 @@ int og_unet_segment_u8_dev(og_unet* h, const uint8_t* gray, int B, int H, int W,
     if (area) HIPCHK(hipMemsetAsync(area, 0, (size_t)B * sizeof(int32_t), h->stream));
     const size_t HW = (size_t)H * W;
     const int n_chunks = (B + h->chunk - 1) / h->chunk;
-    og_unet* t = (h->dual && h->twin && n_chunks >= 2) ? h->twin : nullptr;
-    if (t) {  // the twin's chain must see everything enqueued so far on this stream (area memset, caller's H2D copies)
-        if ((rc = ensure_arena(t, cb > t->capB ? cb : t->capB, H, W))) return rc;
-        HIPCHK(hipEventRecord(h->ev_fork, h->stream));
-        HIPCHK(hipStreamWaitEvent(t->stream, h->ev_fork, 0));
+    og_unet* lanes[kMaxLanes] = {h};
+    int n_lanes = 1;
+    // more lanes the smaller the micro-batch: at batch 1 a chain is 23 launches of ~15 us that each fill a fraction of the chip
+    const int want = h->n_lanes ? h->n_lanes : (h->chunk <= 16 ? 3 : 2);   // measured: 3 lanes +15 % at 1 frame/launch, +2 % at 16, -1 % at 32
+    if (h->dual)
+        for (og_unet* t = h->twin; t && n_lanes < want && n_lanes < n_chunks; t = t->twin) lanes[n_lanes++] = t;
+    if (n_lanes > 1) HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+    for (int l = 1; l < n_lanes; ++l) {  // a lane's chain must see everything enqueued so far on this stream (area memset, caller's H2D copies)
+        if ((rc = ensure_arena(lanes[l], cb > lanes[l]->capB ? cb : lanes[l]->capB, H, W))) return rc;
+        HIPCHK(hipStreamWaitEvent(lanes[l]->stream, h->ev_fork, 0));
     }
     int k = 0;
     for (int b0 = 0; b0 < B; b0 += h->chunk, ++k) {
         const int nb = (B - b0 < h->chunk) ? B - b0 : h->chunk;
-        og_unet* lane = (t && (k & 1)) ? t : h;
-        rc = run_chunk(lane, KIND_U8, gray + b0 * HW, nb, H, W, thr, boxes ? boxes + 4 * b0 : nullptr,
+        rc = run_chunk(lanes[k % n_lanes], KIND_U8, gray + b0 * HW, nb, H, W, thr, boxes ? boxes + 4 * b0 : nullptr,
                        mask ? mask + b0 * HW : nullptr, area ? area + b0 : nullptr, logits ? logits + b0 * HW : nullptr);
         if (rc) return rc;
     }
-    if (t) {  // join: whatever follows on this stream (D2H copies, og_unet_sync) also waits for the twin's chain
-        HIPCHK(hipEventRecord(h->ev_join, t->stream));
-        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    for (int l = 1; l < n_lanes; ++l) {  // join: whatever follows on this stream (D2H copies, og_unet_sync) also waits for the lane's chain
+        HIPCHK(hipEventRecord(lanes[l]->ev_join, lanes[l]->stream));
+        HIPCHK(hipStreamWaitEvent(h->stream, lanes[l]->ev_join, 0));
     }
     return OG_OK;
 }
