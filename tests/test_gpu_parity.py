@@ -170,6 +170,12 @@ def test_chunking_and_graphs_are_result_invariant(trained):
         else:
             assert np.array_equal(masks, base[0]) and np.array_equal(areas, base[1]), (chunk, graphs)
             assert np.array_equal(logits, base[2]), (chunk, graphs)  # same kernels, same order: bit-identical
+    for lanes in (1, 2, 3):  # micro-batches of one call alternate over 1..3 streams/arenas: same results
+        m.set_option("lanes", lanes)
+        m.set_chunk(4)
+        masks, areas, logits = m.segment(fr, want_logits=True)
+        assert np.array_equal(masks, base[0]) and np.array_equal(areas, base[1]) and np.array_equal(logits, base[2]), lanes
+    m.set_option("lanes", 0)
     m.set_chunk(32)
     m.set_graphs(True)
     m.set_option("splitk", 1)
