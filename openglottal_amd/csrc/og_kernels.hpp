@@ -1234,7 +1234,11 @@ __global__ __launch_bounds__(256, (TH >= 16) ? 1 : 2) void k_conv_mfma_p(ConvArg
                 cached_ntile = n_tile;
             }
             // scratch: the halo buffer of the unit just finished (dead; the next unit's halo sits in the other one)
-            conv_epilogue<NT, MODE, TH>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, sc, sh, halo0 + ((u + 1) & 1) * HALO_BYTES + wave * ((MODE == 0) ? 5120 : 4096));  // no pooled tile without MODE 0: 4 x 4 KB fits the 16 KB halo
+            unsigned char* const scr = halo0 + ((u + 1) & 1) * HALO_BYTES + wave * ((MODE == 0) ? 5120 : 4096);  // no pooled tile without MODE 0: 4 x 4 KB fits the 16 KB halo
+            if (a.act == 1) conv_epilogue_b<NT, MODE, TH, 1, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, sc, sh, scr);
+            else if (a.act == 2 && a.res != nullptr) conv_epilogue_b<NT, MODE, TH, 2, true>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, sc, sh, scr);
+            else if (a.act == 2) conv_epilogue_b<NT, MODE, TH, 2, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, sc, sh, scr);
+            else conv_epilogue_b<NT, MODE, TH, 0, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, sc, sh, scr);
             // the next item's first step DMAs the unit-after-next's halo into this very buffer: every wave must be
             // done with its scratch first
             __syncthreads();
