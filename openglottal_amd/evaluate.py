@@ -84,12 +84,23 @@ def evaluate(frames, gts, unet_model, detector=None, crop_model=None, device=Non
     det_stats = {"tp": 0, "fp": 0, "fn": 0, "n_pos_gt": 0}
     if detector is not None:
         prev = object()
+        # native backend and frames at network size: the YOLO network is per-frame independent -> ONE batched device pass;
+        # only the O(1)/frame temporal state machine (with its per-patient / per-frame resets) stays sequential
+        batch = getattr(getattr(detector, "model", None), "detect_batch", None)
+        shapes = {f.shape[:2] for f in frames}
+        best = None
+        if batch is not None and len(shapes) == 1 and all(v % 32 == 0 for v in next(iter(shapes))):
+            best = batch(np.stack([f if f.ndim == 3 else np.repeat(f[..., None], 3, axis=-1) for f in frames]), detector.conf)
         for i, f in enumerate(frames):
             if reset_every_frame or patients[i] != prev:
                 detector.reset()
                 prev = patients[i]
-            bgr = f if f.ndim == 3 else np.repeat(f[..., None], 3, axis=-1)
-            boxes[i] = detector.detect(bgr)
+            if best is not None:
+                H, W = f.shape[:2]
+                boxes[i] = detector.update(best[i:i + 1, :4], best[i:i + 1, 4], W, H) if best[i, 4] >= 0 else detector.update(None, None, W, H)
+            else:
+                bgr = f if f.ndim == 3 else np.repeat(f[..., None], 3, axis=-1)
+                boxes[i] = detector.detect(bgr)
             gt_pos = bool((gts[i] > 0).any())
             det_stats["n_pos_gt"] += int(gt_pos)
             if boxes[i] is not None:
