@@ -464,3 +464,19 @@ def test_occupancy_kernels_on_partial_tiles_large_batch():
     diff = (masks[:4] > 0) != (ref_mask > 0)
     assert np.all(np.abs(ref_logits[diff]) <= TOL * scale)
     assert np.array_equal(areas, (masks > 0).reshape(B, -1).sum(1))
+    # channel counts that are not multiples of 32 (padded channel slots, 64-wide and 128-wide column tiles) at a batch
+    # that takes the occupancy kernels, against the oracle
+    feats2 = (33, 66)
+    sd2 = synth.make_unet_state_dict(feats2, seed=99, head_scale=2.0, head_bias=-0.3)
+    m2 = make_model(sd2, feats2)
+    fr2 = synth.random_gray_frames(128, 32, 64, seed=5)
+    m2.set_chunk(128)
+    masks2, areas2, logits2 = m2.segment(fr2, want_logits=True)
+    ref_mask2, ref_logits2 = O.segment_frames(sd2, fr2[:4], backend="torch")
+    scale2 = max(1.0, np.abs(ref_logits2).max())
+    assert np.abs(logits2[:4] - ref_logits2).max() <= TOL * scale2
+    assert np.all(np.abs(ref_logits2[(masks2[:4] > 0) != (ref_mask2 > 0)]) <= TOL * scale2)
+    m2.set_chunk(2)
+    m2.set_option("splitk", 0)
+    _, areas2b, logits2b = m2.segment(fr2[:6], want_logits=True)
+    assert np.array_equal(logits2[:6], logits2b) and np.array_equal(areas2[:6], areas2b)
