@@ -117,7 +117,7 @@ int og_unet_set_chunk(og_unet* h, int frames_per_launch);
 int og_unet_set_graphs(og_unet* h, int enable);
 
 /* Kernel-selection knobs for A/B measurements (results are bit-identical across them):
- * "conv_impl" 0|1, "tps_nt1" 1|3|9, "tps_nt2" 1|3, "wg_per_cu" 1|2, "prio_mode" 0|1|2, "tile_h" 0|8|16,
+ * "conv_impl" 0|1, "tps_nt1" 1|3|9, "tps_nt2" 1|3, "wg_per_cu" 1|2, "prio_mode" 0|1|2|3, "tile_h" 0|8|16,
  * "splitk_fused" 0|1 (the last-arriving K part of a tile reduces all parts in split order and runs the epilogue; 0: separate reduce launch),
  * "splitk_occ" 0|1 (K parts of a split launch on the occupancy kernel; 0: persistent kernel), "splitk_slots" 1..4 and "splitk_div" 1..8
  * (its target workgroups per CU / split when the launch fills less than 1/div of them),

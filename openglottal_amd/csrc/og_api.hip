@@ -110,7 +110,8 @@ struct og_unet {
     int occ_min_pct = 100; // occupancy kernel when workgroups >= pct % of the CU count (0: one full round of 2-3 per CU);
                            // measured 25..300 at 2..32 frames per launch: 100 is best or within 1 % everywhere
     int tps_nt2 = 1;     // taps per step for the 64-column kernel
-    int prio_mode = 2;   // see ConvArgs::prio_mode (measured +1.2 % on the frame loop)
+    int prio_mode = 3;   // see ConvArgs::prio_mode: 3 = occupancy kernel raises its priority outside the main loop (+0.2-0.4 %
+                         // after the VALU diet; 0 before it) and the persistent kernel alternates as in mode 2 (+1.2 % there)
     // Two lanes: odd micro-batches of one call run on a twin handle (own stream, arena, graphs; SHARED weights), so
     // the launch tails of one chain are filled by the other chain's kernels (+2-4 % measured, tools/two_streams.py).
     og_unet* twin = nullptr;
@@ -1158,7 +1159,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "splitk_div" && value >= 1 && value <= 8) slot = &h->splitk_div;
     else if (n == "occ_min_pct" && value >= 0 && value <= 400) slot = &h->occ_min_pct;
     else if (n == "wg_per_cu" && value >= 1 && value <= 2) slot = &h->wg_per_cu;
-    else if (n == "prio_mode" && value >= 0 && value <= 2) slot = &h->prio_mode;
+    else if (n == "prio_mode" && value >= 0 && value <= 3) slot = &h->prio_mode;
     else if (n == "splitk" && (value == 0 || value == 1)) slot = &h->splitk;
     else if (n == "tile_h" && (value == 0 || value == 8 || value == 16)) slot = &h->tile_h;
     else if (n == "convt_occ" && (value == 0 || value == 1)) slot = &h->convt_occ;

@@ -143,7 +143,8 @@ struct ConvArgs {
     int ksplit;             // >1: split-K.  Item = (tile, K-range); raw accumulators go to `partial`, and
     float* partial;         // k_splitk_epilogue sums them in split order and runs the epilogue (small-batch latency mode)
     int* tile_counter;      // k_conv_mfma_o split-K, fused reduce: arrivals per tile (zero between launches); nullptr = separate epilogue kernel
-    int prio_mode;          // 0 off; 1/2: alternate s_setprio per unit, role = upper half of the grid / odd block
+    int prio_mode;          // 0 off; 1/2: k_conv_mfma_p alternates s_setprio per unit, role = upper half of the grid / odd block;
+                            // 3: as 2, and k_conv_mfma_o runs its set-up and epilogue at raised priority
     unsigned long long* stamps;  // diagnostic only (nullptr in production): per workgroup
                                  // k_conv_mfma_p: 4 x u64 {s_memtime, s_memrealtime} at entry and exit -> in-kernel clock
                                  // k_conv_mfma_o: 8 x u64 {entry, prologue done, main loop done, stores done, HW_ID, XCC_ID}
