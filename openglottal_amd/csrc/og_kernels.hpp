@@ -10,9 +10,17 @@
 // transposed convolutions run as im2col-free implicit GEMMs on the exact-f32
 // matrix pipe: v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD, bit-identical to an
 // fmaf chain, MI355X_MICROARCH.md "Matrix cores").  A = pixels (rows) x input
-// channels, B = input channels x output channels, staged through LDS by
-// global_load_lds_dwordx4 (LDS-DMA) with an XOR-swizzled 128-B-row image so the
-// ds_read_b128 fragment reads are (near) bank-conflict-free.
+// channels, B = input channels x output channels, staged through LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds in the default kernel, global_load_lds_dwordx4 in
+// the older variants) with an XOR-swizzled 128-B-row image so the ds_read_b128
+// fragment reads are bank-conflict-free.
+//
+// Kernel generations, all bit-identical per output element (tests pin that):
+//   k_conv_mfma    gen 1, one tile per workgroup, double-buffered halo (reference variant, conv_impl 0)
+//   k_conv_mfma_p  persistent workgroups, cross-tile prefetch, split-K (launches below one workgroup per CU)
+//   k_conv_mfma_o  occupancy variant = the default: no vector-ALU instruction in the MFMA loop, lean epilogue
+//                  (conv_epilogue_b), MODE 0 3x3 / 1 transposed / 2 1x1 / 3 3x3 stride 2, fused first layer and head,
+//                  split-K with fused reduce.  DESIGN.md section 4 has the measurements behind each choice.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
