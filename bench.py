@@ -197,8 +197,9 @@ def main() -> None:
         fl, ms = sum(p["flops"] for p in dom), sum(p["ms"] for p in dom)
         tot_ms = sum(p["ms"] for p in prof)
         ach = fl / (ms * 1e-3) / 1e12
+        tr = pmc_traffic(DOMINANT, B)   # HBM bytes per launch from the committed rocprofv3 PMC passes (or None)
         out["roofline"] = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(DOMINANT, B),
+                           "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": (tr or {}).get("hbm_bytes_per_launch"), "traffic_detail": tr,
                            "launches_per_chain": len(dom), "avg_launch_ms": round(ms / len(dom), 4),
                            "share_of_chain_time": round(ms / tot_ms, 3), "frames_per_launch": B,
                            "chain_ms": round(tot_ms, 3)}
