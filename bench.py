@@ -166,7 +166,7 @@ def main() -> None:
     if rank == 0:
         fps = args.steps * n_total / el
         out = {
-            "metric": "frames/sec 256x256 U-Net-only", "value": round(fps, 1), "unit": "frames/s",
+            "metric": "frames/sec 256\u00d7256 U-Net-only", "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "U-Net-only 256x256 grayscale synthetic video, features (32,64,128,256), "
