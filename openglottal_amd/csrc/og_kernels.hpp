@@ -1466,11 +1466,14 @@ __global__ __launch_bounds__(256) void k_conv_direct(const void* __restrict__ in
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      int Cout_p, float* __restrict__ out, long long out_frame_stride,
                                                      int out_pix_stride, int out_ch_off, int Hout, int Wout, int ks, int stride,
-                                                     int pad, int act, int total_quads /* B*Hout*ceil(Wout/4) */) {
+                                                     int pad, int act, int total_quads /* B*Hout*ceil(Wout/4) */,
+                                                     int cq_shift /* log2(channel quads worked on per 32-channel group): 3 = all
+                                                                     eight; 2 when only 16 of the 32 padded channels are real, ... */) {
     // thread = (4 consecutive output pixels along x) x (4 output channels): 16 accumulators, so one
     // weight float4 and four input values feed 16 FMAs (the first version did 4 FMAs per 2 loads).
-    const int cq = threadIdx.x & 7;
-    const int q = blockIdx.x * 32 + (threadIdx.x >> 3);
+    // Padded output channels (zero weights; their slots stay at the arena's initial zeros) get no thread at all.
+    const int cq = threadIdx.x & ((1 << cq_shift) - 1);
+    const int q = (blockIdx.x * 256 + threadIdx.x) >> cq_shift;
     if (q >= total_quads) return;
     const int qpr = (Wout + 3) >> 2;  // quads per output row
     const int row = q / qpr;
