@@ -159,3 +159,33 @@ def test_eval_harness_batches_the_detector_without_changing_results(det):
     assert batched[2] == per_frame[2]
     for pipe in E.PIPELINES:
         assert batched[0][pipe]["dice"] == per_frame[0][pipe]["dice"] and batched[0][pipe]["n_det"] == per_frame[0][pipe]["n_det"]
+
+
+def test_cli_run_both_pipelines_end_to_end(tmp_path):
+    """`python -m openglottal_amd.cli run` (counterpart of openglottal/cli.py:46-103): .npy video + torch state_dict +
+    detector .npz in, features.json out, for the U-Net-only and the detection-gated pipeline."""
+    import json
+    import torch
+    from openglottal_amd import cli
+    from openglottal_amd.features import extract_features_unet
+    feats = (32, 64, 128, 256)
+    sd = synth.make_unet_state_dict(feats, seed=5, head_scale=3.0, head_bias=-2.5)
+    torch.save(synth.state_dict_to_torch(sd), tmp_path / "unet.pt")
+    ysd = synth.make_yolov8_state_dict(seed=7)
+    np.savez(tmp_path / "yolo.npz", **ysd)
+    gray, _ = synth.glottis_frames(2, 12)
+    video = np.repeat(gray[..., None], 3, axis=-1)
+    np.save(tmp_path / "video.npy", video)
+    for pipe, extra in (("unet-only", []), ("unet", ["--yolo-weights", str(tmp_path / "yolo.npz")])):
+        out = tmp_path / pipe
+        rc = cli.main(["run", str(tmp_path / "video.npy"), "--pipeline", pipe, "--unet-weights", str(tmp_path / "unet.pt"),
+                       "--device", "cuda:0", "-o", str(out)] + extra)
+        assert rc in (0, 1)
+        if rc == 0:
+            got = json.load(open(out / "features.json"))
+            assert got["pipeline"] == pipe and {"area_mean", "area_std", "area_range", "open_quotient", "f0", "periodicity", "cv"} <= set(got)
+            m = og.UNet(1, 1, feats); m.load_state_dict(sd); m.to("cuda:0").eval()
+            det = og.TemporalDetector(str(tmp_path / "yolo.npz")) if pipe == "unet" else None
+            ref = extract_features_unet(str(tmp_path / "video.npy"), det, m, "cuda:0")
+            for k in ("area_mean", "area_std", "area_range", "open_quotient", "periodicity", "cv"):
+                assert got[k] == pytest.approx(float(ref[k]), rel=0, abs=0)
