@@ -101,6 +101,8 @@ def main() -> None:
                     help="2 = odd micro-batches on the twin handle's stream (default); 1 = single stream "
                          "(per-kernel durations under rocprofv3 are then not inflated by the other lane)")
     ap.add_argument("--no-latency-mode", action="store_true", help="skip the 1-frame-per-launch leg")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="og_unet_set_option knob for A/B measurements (results are bit-identical across them), repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -131,6 +133,9 @@ def main() -> None:
     model.set_chunk(args.chunk)
     model.set_graphs(not args.no_graphs)
     model.set_option("dual", 1 if args.lanes == 2 else 0)
+    for kv in args.option:
+        k, v = kv.split("=")
+        model.set_option(k, int(v))
 
     F = args.frames
     n_total = F * world

@@ -104,6 +104,7 @@ struct og_unet {
     int conv_impl = 2;   // 0 k_conv_mfma | 1 k_conv_mfma_p (persistent, pipelined) | 2 auto: k_conv_mfma_o (3 WG/CU, single halo
                          // buffer) for full launches, k_conv_mfma_p + split-K for launches that cannot fill the chip | 3 k_conv_mfma_o, 4 WG/CU
     int tps_nt1 = 3;     // taps per step for the 32-column kernel
+    int xcd_group = 1;   // see LaunchCtx::xcd_group
     int splitk_occ = 1;  // split-K parts on the occupancy kernel (0: persistent kernel)
     int splitk_min_steps = 9;  // smallest K part of a split 3x3 conv, in (chunk, tap) steps (9 = one channel chunk)
     int splitk_slots = 2, splitk_div = 4;  // occupancy split-K: target workgroups per CU; split when the launch fills < 1/div of them
@@ -363,6 +364,7 @@ struct LaunchCtx {
     hipStream_t stream;
     int n_cu;
     int wg_per_cu;
+    int xcd_group = 1;   // occupancy kernel: frame-interleaved grid.z so that a tile's column tiles share an XCD
 };
 
 constexpr int kMaxLanes = 3;   // a fourth lane measured slower than three at every micro-batch size
@@ -397,10 +399,19 @@ int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     if (MODE != 0 && MODE != 1) a.ksplit = 1;
     const int frames = a.n_spatial / (a.tiles_x * a.tiles_y);
     a.zdiv = n_ntiles * a.ksplit;
-    a.zrcp = 1.0f / (float)a.zdiv;
-    if ((long long)frames * a.zdiv > 65535) return fail(OG_EINVAL, "micro-batch too large for one launch (grid.z): lower the chunk size");
+    a.frames = frames;
+    a.zgroup_shift = 0;
+    if (c.xcd_group && a.zdiv > 1) {   // column tiles of one spatial tile onto one XCD (8 XCDs, blocks dealt round-robin)
+        int txy = a.tiles_x * a.tiles_y, g = 8;
+        while (g > 1 && txy % 2 == 0) { txy /= 2; g /= 2; }   // g = 8 / gcd(8, tiles per frame)
+        while (g > frames) g /= 2;
+        while ((1 << a.zgroup_shift) < g) ++a.zgroup_shift;
+    }
+    const int G = 1 << a.zgroup_shift, groups = (frames + G - 1) / G;
+    a.zrcp = 1.0f / (float)(a.zdiv * G);
+    if ((long long)groups * G * a.zdiv > 65535) return fail(OG_EINVAL, "micro-batch too large for one launch (grid.z): lower the chunk size");
     if (a.ksplit == 1 || a.n_spatial * n_ntiles > 4096) a.tile_counter = nullptr;
-    hipLaunchKernelGGL((k_conv_mfma_o<NT, MODE, TH, OCC>), dim3(a.tiles_x, a.tiles_y, frames * a.zdiv), dim3(256), lds, c.stream, a);
+    hipLaunchKernelGGL((k_conv_mfma_o<NT, MODE, TH, OCC>), dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), lds, c.stream, a);
     HIPCHK(hipGetLastError());
     if (a.ksplit > 1 && a.tile_counter == nullptr) {
         hipLaunchKernelGGL((k_splitk_epilogue<NT, MODE, TH>), dim3(a.n_spatial * n_ntiles), dim3(256), 4 * 5120, c.stream, a);
@@ -513,7 +524,7 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     a.res_frame_stride = 0;
     a.res_pix_stride = 0;
     a.res_ch_off = 0;
-    const LaunchCtx ctx{h->stream, h->n_cu, h->wg_per_cu};
+    const LaunchCtx ctx{h->stream, h->n_cu, h->wg_per_cu, h->xcd_group};
     a.prio_mode = h->prio_mode;
     a.first_u8 = nullptr;
     a.first_w9 = nullptr;
@@ -718,6 +729,8 @@ int enqueue_first_fused(og_unet* h, const uint8_t* gray, int B, int H, int W) {
                2.0 * B * H * W * 9.0 * (1.0 * h->features[0] + (double)h->features[0] * h->features[0]));
     a.zdiv = 1;
     a.zrcp = 1.0f;
+    a.zgroup_shift = 0;
+    a.frames = B;
     hipLaunchKernelGGL((k_conv_mfma_o<1, 0, 8, 3, true>), dim3(a.tiles_x, a.tiles_y, B), dim3(256), lds, h->stream, a);
     prof_end(h);
     HIPCHK(hipGetLastError());
@@ -1152,6 +1165,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     if (n == "conv_impl" && value >= 0 && value <= 3) slot = &h->conv_impl;
     else if (n == "tps_nt1" && (value == 1 || value == 3 || value == 9)) slot = &h->tps_nt1;
     else if (n == "tps_nt2" && (value == 1 || value == 3)) slot = &h->tps_nt2;
+    else if (n == "xcd_group" && (value == 0 || value == 1)) slot = &h->xcd_group;
     else if (n == "splitk_occ" && (value == 0 || value == 1)) slot = &h->splitk_occ;
     else if (n == "splitk_fused" && (value == 0 || value == 1)) slot = &h->splitk_fused;
     else if (n == "splitk_slots" && value >= 1 && value <= 4) slot = &h->splitk_slots;

@@ -146,8 +146,10 @@ struct ConvArgs {
     uint8_t* head_mask;
     int32_t* head_area;
     int head_store_act;     // also store the activation tensor (parity/debug taps)
-    int zdiv;               // k_conv_mfma_o's grid.z = frame * zdiv + (column tile * ksplit + K part); zrcp = 1 / zdiv
-    float zrcp;
+    int zdiv;               // k_conv_mfma_o's grid.z: zdiv = column tiles * ksplit (see the decode in the kernel)
+    float zrcp;             // 1 / (zdiv << zgroup_shift)
+    int zgroup_shift;       // log2 of the frames per z group
+    int frames;             // B
     int ksplit;             // >1: split-K.  Item = (tile, K-range); raw accumulators go to `partial`, and
     float* partial;         // k_splitk_epilogue sums them in split order and runs the epilogue (small-batch latency mode)
     int* tile_counter;      // k_conv_mfma_o split-K, fused reduce: arrivals per tile (zero between launches); nullptr = separate epilogue kernel
@@ -693,9 +695,16 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     //      on the way to the first DMA (each one is ~20 vector-ALU instructions, paid at the contended issue rate).
     //      split-K (latency mode, MODE 0/1): K part = a range of (chunk, tap) steps ----
     const int ks_n = (MODE == 0 || MODE == 1) ? a.ksplit : 1;
+    // grid.z = frame group q x (column tile, K part) x frame-in-group: the column tiles of one spatial tile then sit
+    // G * tiles_x * tiles_y (a multiple of 8) blocks apart = on the same XCD, dispatched together, and share the input
+    // tile in that XCD's L2 (G = 2^zgroup_shift frames per group; 1 when tiles_x * tiles_y is already a multiple of 8)
     const int bz = (int)blockIdx.z;
-    const int b = (a.zdiv == 1) ? bz : (int)(((float)bz + 0.5f) * a.zrcp);   // zdiv = column tiles x K parts; exact for bz < 2^16
-    const int zr = bz - b * a.zdiv;
+    const int gz = a.zdiv << a.zgroup_shift;
+    const int q = (gz == 1) ? bz : (int)(((float)bz + 0.5f) * a.zrcp);   // zrcp = 1 / gz; exact for bz < 2^16
+    const int rz = bz - q * gz;
+    const int zr = rz >> a.zgroup_shift;                                   // column tile x K parts + K part
+    const int b = (q << a.zgroup_shift) + (rz & ((1 << a.zgroup_shift) - 1));
+    if (b >= a.frames) return;   // tail of the last frame group (whole workgroup, before any barrier)
     const int n_tile = (ks_n == 1) ? zr : zr / ks_n;
     const int kpart = (ks_n == 1) ? 0 : zr - n_tile * ks_n;
     constexpr int TAPS_ = (MODE == 0) ? 9 : 1;

@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
     a.H = HW; a.W = HW; a.tiles_x = HW / 16; a.tiles_y = HW / TH; a.n_spatial = B * a.tiles_x * a.tiles_y;
     a.wpk = dw; a.scale = dsc; a.shift = dsh; a.aff_mod = Cout;
     a.out = dout; a.out_frame_stride = (long long)HW * HW * Cout; a.out_pix_stride = Cout;
-    a.zero_page = dz; a.act = 1; a.ksplit = 1; a.zdiv = 1; a.zrcp = 1.0f;
+    a.zero_page = dz; a.act = 1; a.ksplit = 1; a.zdiv = 1; a.zrcp = 1.0f; a.zgroup_shift = 0; a.frames = B;
     a.prio_mode = (argc > 6) ? atoi(argv[6]) : 0;
     const int grid = a.n_spatial;
     CK(hipMalloc(&dst, (size_t)grid * 64));
