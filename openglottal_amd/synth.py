@@ -136,6 +136,18 @@ def glottis_frames(
     return np.stack(frames), np.stack(gts)
 
 
+def full128_frames() -> tuple[np.ndarray, np.ndarray]:
+    """The 128 frames of the bench-configuration fixture (tests/golden/unet_full128.npz): the 80-frame structured
+    GIRAFE stand-in (4 "patients" x 20 frames, ``glottis_frames(4, 20, seed=99)``) followed by frames 0..47 of the
+    throughput stream (``bench_frame_bgr(i)`` = ``RandomState(1234+i)``) through BGR->gray.
+    Returns ``(gray [128,256,256] u8, gt [80,256,256] u8)``."""
+    from .utils import bgr_to_gray
+
+    glot, gt = glottis_frames(4, 20, seed=99)
+    stream = np.stack([bgr_to_gray(bench_frame_bgr(i)) for i in range(48)])
+    return np.concatenate([glot, stream], axis=0), gt
+
+
 # ── YOLOv8 detector weights (ultralytics state_dict keys) ────────────────────
 
 

@@ -107,6 +107,55 @@ def packbits(mask: np.ndarray) -> np.ndarray:
     return np.packbits((mask > 0).astype(np.uint8).ravel())
 
 
+
+def gen_full128(UNet, unet_segment_frame, dice, iou, meta) -> None:
+    """(7) C1 at full width + the bench configuration's pin: the reference's own `unet_segment_frame` (utils.py:218-241)
+    and `UNet.forward` on 128 frames at features (32,64,128,256) with the seeded + calibrated weights of section (1).
+    Stored: bit-packed masks, integer areas, 1024 sampled logits per frame, Dice/IoU vs GT for the 80 structured frames
+    as `frame_metrics` / `dice` compute them (eval_girafe.py:113-124), and EVERY pixel whose |logit| < 1e-3 (index +
+    value) so that a test can apply the flip rule (a pixel may differ only where |reference logit| <= 5e-5) from the
+    reference's numbers alone."""
+    import torch
+
+    from openglottal_amd import synth
+
+    g1 = np.load(os.path.join(HERE, "unet_full.npz"))
+    feats = tuple(int(f) for f in g1["features"])
+    sd = synth.make_unet_state_dict(feats, seed=int(g1["seed"]), head_scale=float(g1["head_scale"]), head_bias=float(g1["head_bias"]))
+    model = UNet(1, 1, feats)
+    model.load_state_dict(synth.state_dict_to_torch(sd))
+    model.eval()
+    frames, gt = synth.full128_frames()
+    dev = torch.device("cpu")
+    masks = np.stack([unet_segment_frame(f, model, dev) for f in frames])           # the reference call, one frame at a time
+    logits = np.empty((128, 256, 256), np.float32)
+    with torch.no_grad():
+        for i in range(128):                                                           # batch 1, as the reference runs it
+            logits[i] = model(torch.from_numpy(frames[i:i + 1].astype("float32") / 255.0).unsqueeze(1)).numpy()[0, 0]
+    assert np.array_equal(masks > 0, logits > 0), "sigmoid>0.5 vs logit>0 disagree on reference output"
+    areas = np.array([int(np.sum(m > 0)) for m in masks], dtype=np.int64)
+    samp = np.random.RandomState(6).choice(256 * 256, size=1024, replace=False).astype(np.int32)
+    flat = logits.reshape(128, -1)
+    near = np.argwhere(np.abs(flat) < 1e-3)                                            # [n, 2] (frame, pixel)
+    np.savez_compressed(
+        os.path.join(HERE, "unet_full128.npz"),
+        features=np.array(feats), seed=int(g1["seed"]), head_scale=float(g1["head_scale"]), head_bias=float(g1["head_bias"]),
+        masks_packed=np.stack([packbits(m) for m in masks]),
+        areas=areas,
+        sample_idx=samp,
+        logits_samples=flat[:, samp].astype(np.float32),
+        near_zero_frame=near[:, 0].astype(np.int32), near_zero_pixel=near[:, 1].astype(np.int32),
+        near_zero_logit=flat[near[:, 0], near[:, 1]].astype(np.float32),
+        abs_logit_min=np.abs(flat).min(axis=1),
+        dice_vs_gt=np.array([dice(masks[i], gt[i]) for i in range(80)]),
+        iou_vs_gt=np.array([iou(masks[i], gt[i]) for i in range(80)]),
+    )
+    meta["unet_full128"] = {"areas_first8": areas[:8].tolist(), "areas_stream_first4": areas[80:84].tolist(),
+                            "n_abs_logit_lt_1e3": int(len(near)), "n_abs_logit_le_5e5": int((np.abs(flat) <= 5e-5).sum()),
+                            "mean_dice_vs_gt_80": float(np.mean([dice(masks[i], gt[i]) for i in range(80)]))}
+    print("full128: areas", areas[:4], areas[80:84], "near-zero pixels", len(near), "min|logit|", np.abs(flat).min())
+
+
 def main() -> None:
     install_placeholders()
     import torch
@@ -124,6 +173,13 @@ def main() -> None:
 
     dev = torch.device("cpu")
     meta: dict = {"torch": torch.__version__, "numpy": np.__version__, "threads": torch.get_num_threads()}
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "full128":
+        # regenerate section (7) alone; every other fixture (and the rest of meta.json) stays as committed
+        meta = json.load(open(os.path.join(HERE, "meta.json")))
+        gen_full128(UNet, unet_segment_frame, dice, iou, meta)
+        with open(os.path.join(HERE, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1)
+        return
 
     # ── (1) full-width U-Net, seeded weights, calibrated head ────────────────
     feats = (32, 64, 128, 256)
@@ -328,6 +384,9 @@ def main() -> None:
     boxes = [[100, 80, 160, 200], [0, 0, 256, 256], [120, 120, 121, 121], [30, 40, 30, 90]]
     gated = [[int(np.sum(ev_masks[i][b[1]:b[3], b[0]:b[2]] > 0)) for b in boxes] for i in range(8)]
     meta["gated"] = {"boxes": boxes, "areas_first8": gated}
+
+    # ── (7) full width, 128 frames: C1 stand-in + the bench configuration's pin ──
+    gen_full128(UNet, unet_segment_frame, dice, iou, meta)
 
     with open(os.path.join(HERE, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1)

@@ -1,0 +1,114 @@
+"""-m gpu: bench.py's exact configuration against the reference.
+
+128 full-width (32,64,128,256) frames — the 80-frame structured GIRAFE stand-in (C1) + 48 frames of the seeded
+throughput stream (C2) — run exactly as `bench.py` runs them: device-resident u8 frames, 64 frames per kernel chain,
+two lanes, hipGraph replay, fused first layer and fused head.  Masks, areas, sampled logits and Dice vs GT are checked
+against tests/golden/unet_full128.npz, which tests/golden/gen_golden.py captured from the reference's own
+`unet_segment_frame` (openglottal/utils.py:218-241) and metric definitions (scripts/eval_girafe.py:113-124).
+
+Flip rule (as test_gpu_parity.py): a mask pixel may differ from the reference only where the REFERENCE's logit is
+within 5e-5 of zero (fp32 re-association noise; the reference is not bit-reproducible across oneDNN thread counts);
+the area may differ by at most the number of such flips.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import openglottal_amd as og
+from openglottal_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 5e-5
+DOMINANT = "k_conv_mfma_o<2,0,16>"
+
+
+def unpack(bits, h=256, w=256):
+    return np.unpackbits(bits)[: h * w].reshape(h, w)
+
+
+@pytest.fixture(scope="module")
+def setup(golden_dir):
+    import torch
+
+    g = np.load(os.path.join(golden_dir, "unet_full128.npz"))
+    feats = tuple(int(f) for f in g["features"])
+    sd = synth.make_unet_state_dict(feats, seed=int(g["seed"]), head_scale=float(g["head_scale"]), head_bias=float(g["head_bias"]))
+    m = og.UNet(1, 1, feats)
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    m.set_chunk(64)            # bench.py --chunk default
+    m.set_graphs(True)         # bench.py default
+    m.set_option("dual", 1)    # bench.py --lanes 2
+    frames, gt = synth.full128_frames()
+    dev = torch.device("cuda", 0)
+    return g, m, frames, gt, torch.from_numpy(frames).to(dev), dev
+
+
+def check_against_fixture(g, masks, areas, logits, gt):
+    nz = {(int(f), int(p)): float(v) for f, p, v in zip(g["near_zero_frame"], g["near_zero_pixel"], g["near_zero_logit"])}
+    n = len(masks)
+    flips_total = 0
+    for i in range(n):
+        ref = unpack(g["masks_packed"][i]) > 0
+        flips = np.flatnonzero(((masks[i] > 0) != ref).ravel())
+        for p in flips:
+            assert abs(nz.get((i, int(p)), 1.0)) <= TOL, (i, int(p), nz.get((i, int(p))))
+        flips_total += len(flips)
+        assert int(areas[i]) == int((masks[i] > 0).sum())
+        assert abs(int(areas[i]) - int(g["areas"][i])) <= len(flips), i
+        if logits is not None:
+            assert np.abs(logits[i].ravel()[g["sample_idx"]] - g["logits_samples"][i]).max() <= TOL, i
+    d = np.array([og.dice(masks[i], gt[i]) for i in range(80)])
+    assert np.abs(d - g["dice_vs_gt"]).max() <= 1e-3                 # per frame
+    assert abs(d.mean() - float(g["dice_vs_gt"].mean())) <= 1e-3     # the table's mean (eval_girafe.py:363)
+    return flips_total
+
+
+def test_bench_configuration_against_reference_fixture(setup):
+    import torch
+
+    g, m, frames, gt, fdev, dev = setup
+    area = torch.zeros(128, dtype=torch.int32, device=dev)
+    mask = torch.zeros((128, 256, 256), dtype=torch.uint8, device=dev)
+    logits = torch.zeros((128, 256, 256), dtype=torch.float32, device=dev)
+    for rep in range(2):   # first pass captures the hipGraphs of both lanes, second pass replays them
+        area.zero_(); mask.zero_(); logits.zero_()
+        torch.cuda.synchronize()
+        m.segment_dev(fdev, 128, 256, 256, area, mask_dev=mask, logits_dev=logits)
+        m.sync()
+        flips = check_against_fixture(g, mask.cpu().numpy(), area.cpu().numpy(), logits.cpu().numpy(), gt)
+        print(f"pass {rep}: flipped pixels {flips} of {128 * 65536}")
+    # areas only (what bench.py's timed step asks for): same integers
+    area2 = torch.zeros(128, dtype=torch.int32, device=dev)
+    m.segment_dev(fdev, 128, 256, 256, area2)
+    m.sync()
+    assert torch.equal(area, area2)
+    # the chain really is the bench's: fused first layer, the 16x16-tile occupancy kernel on the ten deep layers, fused head
+    prof = m.profile(fdev, 64, 256, 256, reps=1)
+    kernels = [p["kernel"] for p in prof]
+    assert kernels.count(DOMINANT) == 10, kernels
+    assert kernels[0] == "k_conv_mfma_o<1,0,8,FIRST>", kernels
+    assert "k_head" not in kernels and "k_conv_first<u8>" not in kernels, kernels
+    assert all(k.startswith("k_conv_mfma_o") for k in kernels), kernels
+
+
+def test_bench_configuration_host_entry_and_latency_mode(setup):
+    """Same 128 frames through the host-pointer entry (og_unet_segment_u8) and, for the first 16, at one frame per
+    kernel chain (bench.py's latency_mode: split-K with fused reduce, three lanes)."""
+    g, m, frames, gt, fdev, dev = setup
+    masks, areas, logits = m.segment(frames, want_logits=True)
+    check_against_fixture(g, masks, areas, logits, gt)
+    m.set_chunk(1)
+    try:
+        mk1, ar1, lg1 = m.segment(frames[:16], want_logits=True)
+    finally:
+        m.set_chunk(64)
+    nz = {(int(f), int(p)): float(v) for f, p, v in zip(g["near_zero_frame"], g["near_zero_pixel"], g["near_zero_logit"])}
+    for i in range(16):
+        flips = np.flatnonzero(((mk1[i] > 0) != (unpack(g["masks_packed"][i]) > 0)).ravel())
+        for p in flips:
+            assert abs(nz.get((i, int(p)), 1.0)) <= TOL
+        assert abs(int(ar1[i]) - int(g["areas"][i])) <= len(flips)
+        assert np.abs(lg1[i].ravel()[g["sample_idx"]] - g["logits_samples"][i]).max() <= TOL

@@ -93,3 +93,24 @@ def test_trained_small_80_frames_bit_exact(golden_dir):
         assert np.array_equal(masks[i] > 0, unpack(g["masks_packed"][i]) > 0), i
     assert np.array_equal(O.areas_from_masks(masks), g["areas"])
     assert np.abs(logits[:, 128, :] - g["logits_row128"]).max() <= 1e-4
+
+
+def test_full_width_128_frame_fixture_subset(golden_dir):
+    """The oracle against the 128-frame full-width fixture (the reference's `unet_segment_frame` on the 80-frame
+    structured stand-in + 48 frames of the seeded throughput stream): 12 frames here (CPU time), all 128 on the GPU."""
+    g = np.load(os.path.join(golden_dir, "unet_full128.npz"))
+    sd = synth.make_unet_state_dict(tuple(g["features"]), seed=int(g["seed"]),
+                                    head_scale=float(g["head_scale"]), head_bias=float(g["head_bias"]))
+    frames, gt = synth.full128_frames()
+    sel = [0, 19, 20, 41, 63, 79, 80, 81, 95, 110, 126, 127]
+    masks, logits = O.segment_frames(sd, frames[sel], backend="torch")
+    nz = {(int(f), int(p)): float(v) for f, p, v in zip(g["near_zero_frame"], g["near_zero_pixel"], g["near_zero_logit"])}
+    for j, i in enumerate(sel):
+        assert np.abs(logits[j].ravel()[g["sample_idx"]] - g["logits_samples"][i]).max() <= LOGIT_TOL, i
+        flips = np.flatnonzero(((masks[j] > 0) != (unpack(g["masks_packed"][i]) > 0)).ravel())
+        for p in flips:   # the REFERENCE's logit at a flipped pixel must be within tolerance of zero
+            assert abs(nz.get((i, int(p)), 1.0)) <= LOGIT_TOL, (i, int(p))
+        assert abs(int((masks[j] > 0).sum()) - int(g["areas"][i])) <= len(flips)
+        if i < 80:
+            from openglottal_amd.utils import dice
+            assert abs(dice(masks[j], gt[i]) - float(g["dice_vs_gt"][i])) <= 1e-3
