@@ -165,6 +165,16 @@ class UNet:
               "og_unet_segment_crops_u8")
         return out
 
+    def bgr2gray_dev(self, bgr_dev, B: int, H: int, W: int, gray_dev) -> None:
+        """``cv2.cvtColor(BGR2GRAY)`` (features.py:235) on device buffers ``[B,H,W,3]`` u8 → ``[B,H,W]`` u8, asynchronous."""
+        self._require()
+        check(lib().og_bgr2gray_dev(self._h, ptr(bgr_dev), B, H, W, ptr(gray_dev)), "og_bgr2gray_dev")
+
+    def mask_area_dev(self, mask_dev, B: int, H: int, W: int, boxes_dev, area_dev) -> None:
+        """Box-gated recount ``sum(mask[y1:y2, x1:x2] > 0)`` (features.py:244-245) on resident masks, asynchronous."""
+        self._require()
+        check(lib().og_mask_area_dev(self._h, ptr(mask_dev), B, H, W, ptr(boxes_dev), ptr(area_dev)), "og_mask_area_dev")
+
     def sync(self) -> None:
         self._require()
         check(lib().og_unet_sync(self._h), "og_unet_sync")
