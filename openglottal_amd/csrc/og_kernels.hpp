@@ -85,11 +85,6 @@ __device__ __forceinline__ void glds16b(unsigned voff, og_i32x4 rsrc, unsigned s
         : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_wave_base)
         : "memory");
 }
-// Compiler-only fence for LDS data exchanged inside ONE wave (the LDS itself keeps a wave's accesses in order).
-__device__ __forceinline__ void og_lds_order() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
 __device__ __forceinline__ float og_act(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
     if (act == 2) return v / (1.0f + expf(-v));  // SiLU = x * sigmoid(x)
@@ -400,7 +395,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16* a
             }
             vmaxs[g] = vmax;
         }
-        og_lds_order();  // float writes above, f32x4 reads below, same wave: keep hipcc from reordering them (TBAA)
         // full-resolution tile: 4 x (64 lanes x 16 B)
         const bool fuse_head = (MODE == 0 && NT == 1 && a.head_w != nullptr);
         const bool store_act = !fuse_head || a.head_store_act;
@@ -439,14 +433,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16* a
             // pooled tile: 8 windows x 32 channels = exactly one 16-B store per lane
 #pragma unroll
             for (int g = 0; g < 4; ++g) fs[1024 + (2 * g + lh) * 32 + li] = vmaxs[g];   // scratch bytes [4096, 5120)
-            og_lds_order();
             const f32x4 p4 = *(const f32x4*)(fs + 1024 + rrow * 32 + rc4);
             const int y = ty0 + 2 * ms, x = tx0 + 2 * rrow;
             if (y < a.H && x < a.W)
                 *(f32x4*)(a.pool + (long long)b * a.pool_frame_stride + ((long long)(y >> 1) * (a.W >> 1) + (x >> 1)) * a.pool_pix_stride +
                           a.pool_ch_off + cbase + rc4) = p4;
         }
-        og_lds_order();
     }
     if (MODE == 0 && NT == 1 && a.head_w != nullptr && a.head_area != nullptr) {
         // one plain store per wave into a per-(frame, tile, wave) slot; k_sum_counts adds them up per frame.
@@ -474,6 +466,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t og_rsrc(const void* base, unsi
     const unsigned long long v = (unsigned long long)base;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+// 16-byte store through a raw buffer resource with the wave-uniform part of the address in an SGPR (soffset), followed
+// by ONE WAIT STATE.  The wait state is required on gfx950: a buffer_store_dwordx4 whose data VGPRs are overwritten by
+// the very next instruction (here: the next sub-tile's v_pk_fma_f32) stores garbage in one 16-lane beat of one dword.
+// It is the GFX9 "VMEM store of more than 64 bits, then a VALU write of the write-data VGPRs: 1 wait state" hazard;
+// hipcc's hazard recognizer waives it for stores that use an SGPR soffset (GCNHazardRecognizer::createsVALUHazard), which
+// is exactly this store -- so the nop has to be ours.  Root cause of round 1's "non-repeatable wrong lanes"
+// (profiles/r02_epilogue_fence_audit.md); tests/test_isa_audit.py scans the shipped ISA for the pattern.
+#ifndef OG_STORE_NOP
+#define OG_STORE_NOP 1   // -DOG_STORE_NOP=0: audit build that reproduces the failure
+#endif
+__device__ __forceinline__ void og_buffer_store16(f32x4 v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+#if OG_STORE_NOP
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 0" : : "v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+#else
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(og_u32x4, v), rs, voff, soff, 0);
+#endif
 }
 template <int NT, int MODE, int TH, int ACT, bool RES>
 __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16* acc, int n_tile, int b, int ty0, int tx0, int wm, int wn,
@@ -553,13 +562,9 @@ __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16*
                 vmaxs[g] = (rr == 0) ? v : fmaxf(vmaxs[g], v);
             }
         }
-        // The scratch is written as float and read back as f32x4 by the SAME wave (the LDS keeps a wave's accesses in
-        // order), but type-based alias analysis lets hipcc move such reads above the writes: fence the compiler.
-        og_lds_order();
         f32x4 v4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v4[q] = *(const f32x4*)(fr + q * 256);
-        og_lds_order();
         if (y0 < a.H) {
             const bool half = (y0 + 1 >= a.H);   // odd H (detector maps of 160-pixel inputs): only the first row exists
             if (store_act) {
@@ -567,7 +572,7 @@ __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16*
                 for (int q = 0; q < 4; ++q) {
                     const int so = (MODE == 1) ? (((2 * y0 + (qd >> 1)) * OW + 2 * (tx0 + 4 * q) + (qd & 1)) * a.out_pix_stride + a.out_ch_off + cbase) * 4
                                                : ((y0 * OW + tx0 + 4 * q) * a.out_pix_stride + a.out_ch_off + cbase) * 4;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(og_u32x4, v4[q]), out_rs, (half && yl) ? OG_OOB : vq[q], so, 0);
+                    og_buffer_store16(v4[q], out_rs, (half && yl) ? OG_OOB : vq[q], (unsigned)so);
                 }
             }
             if (MODE == 0 && NT == 1 && fuse_head) {
@@ -605,11 +610,9 @@ __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16*
                 // pooled tile: 8 windows x 32 channels = exactly one 16-B store per lane
 #pragma unroll
                 for (int g = 0; g < 4; ++g) fw[1024 - 96 * lh + g * 64] = vmaxs[g];  // fs[1024 + (2g + lh) * 32 + li]
-                og_lds_order();
                 const f32x4 p4 = *(const f32x4*)(fr + 1024);
-                og_lds_order();
                 const int so = (((y0 >> 1) * (a.W >> 1) + (tx0 >> 1)) * a.pool_pix_stride + a.pool_ch_off + cbase) * 4;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(og_u32x4, p4), pool_rs, vpool, so, 0);
+                og_buffer_store16(p4, pool_rs, vpool, (unsigned)so);
             }
         }
     }

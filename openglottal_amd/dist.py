@@ -99,7 +99,9 @@ def sharded_gated_area_waveform(frames_bgr, detect_batch, make_detector, model, 
     machine over the whole video (deterministic, so all ranks agree); (3) every rank segments its own frames
     with its slice of the boxes; (4) the areas are all-gathered.
 
-    ``detect_batch(frames [n,H,W,3], conf) -> best [n,5]`` (conf = -1: no detection);
+    ``detect_batch(frames [n,H,W,3], conf) -> best [n,5]`` in ORIGINAL-frame pixels (conf = -1: no detection) —
+    pass ``YoloV8Detector.detect_frames`` (letterboxes to the model's imgsz and scales the boxes back, like the
+    per-frame call), not the network-resolution ``detect_batch``;
     ``make_detector()`` returns a fresh ``TemporalDetector`` (only its ``update`` is used).
     """
     import torch

@@ -86,11 +86,11 @@ def evaluate(frames, gts, unet_model, detector=None, crop_model=None, device=Non
         prev = object()
         # native backend and frames at network size: the YOLO network is per-frame independent -> ONE batched device pass;
         # only the O(1)/frame temporal state machine (with its per-patient / per-frame resets) stays sequential
-        batch = getattr(getattr(detector, "model", None), "detect_batch", None)
-        shapes = {f.shape[:2] for f in frames}
+        batch = getattr(getattr(detector, "model", None), "detect_frames", None)
+        shapes = {f.shape for f in frames}
         best = None
-        if batch is not None and len(shapes) == 1 and all(v % 32 == 0 for v in next(iter(shapes))):
-            best = batch(np.stack([f if f.ndim == 3 else np.repeat(f[..., None], 3, axis=-1) for f in frames]), detector.conf)
+        if batch is not None and len(shapes) == 1:   # one size: letterbox + network + scale-back for all frames in one pass
+            best = batch(np.stack(frames), detector.conf)
         for i, f in enumerate(frames):
             if reset_every_frame or patients[i] != prev:
                 detector.reset()

@@ -103,10 +103,11 @@ def area_waveform(frames, detector, model, device=None, threshold: float = 0.5) 
     if detector is not None:
         detector.reset()
         boxes = np.empty((n, 4), np.int32)
-        batch = getattr(detector.model, "detect_batch", None)
-        if batch is not None and len(shapes) == 1 and all(s % 32 == 0 for s in next(iter(shapes))) and frames[0].ndim == 3:
-            # native backend, frames already at network size: the YOLO network is per-frame independent, so run it
-            # batched on the device; only the O(1)/frame temporal state machine (detector.py:61-96) is sequential
+        batch = getattr(detector.model, "detect_frames", None)
+        if batch is not None and len(shapes) == 1 and len({f.ndim for f in frames}) == 1:
+            # native backend, frames of one size: the YOLO network is per-frame independent, so run it batched on the
+            # device (letterboxed to the model's imgsz and scaled back exactly as the per-frame call does); only the
+            # O(1)/frame temporal state machine (detector.py:61-96) is sequential
             best = batch(np.stack(frames), detector.conf)
             H, W = frames[0].shape[:2]
             for i in range(n):

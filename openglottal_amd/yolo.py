@@ -87,23 +87,41 @@ class YoloV8Detector:
         check(lib().og_yolo_detect_u8(self._h, ptr(f), B, H, W, float(conf), ptr(best), ptr(pred)), "og_yolo_detect_u8")
         return (best, pred) if want_pred else best
 
+    def detect_frames(self, frames_bgr, conf: float = 0.25) -> np.ndarray:
+        """Frames of ONE size ``[B,H,W,3]`` (or ``[B,H,W]`` gray) at their ORIGINAL resolution → ``best [B,5]`` in
+        original-frame pixels (conf = -1: no detection): what the ultralytics predictor does per call of
+        ``self.model(frame_bgr, conf=...)`` (detector.py:58) — letterbox to ``imgsz``, network, ``scale_boxes`` back,
+        clip — for the whole batch in one device pass.  ``__call__`` is this with B = 1, so the batched callers
+        (`features.area_waveform`, `evaluate.evaluate`, `dist.sharded_gated_area_waveform`) and the per-frame
+        ``TemporalDetector.detect`` see the same boxes for every frame size, not only where the letterbox is the identity."""
+        f = np.asarray(frames_bgr)
+        if f.ndim == 3:
+            f = np.repeat(f[..., None], 3, axis=-1)
+        B, H0, W0 = f.shape[:3]
+        if B == 0:
+            return np.zeros((0, 5), np.float32)
+        first, gain, px, py = letterbox_bgr(f[0], self.imgsz)
+        if first.shape == f[0].shape and (gain, px, py) == (1.0, 0, 0):
+            imgs = f
+        else:
+            imgs = np.stack([first] + [letterbox_bgr(x, self.imgsz)[0] for x in f[1:]])
+        best = self.detect_batch(imgs, conf).copy()
+        hit = best[:, 4] >= 0
+        if (gain, px, py) != (1.0, 0, 0):  # scale_boxes back to the original frame
+            best[:, [0, 2]] = (best[:, [0, 2]] - np.float32(px)) / np.float32(gain)
+            best[:, [1, 3]] = (best[:, [1, 3]] - np.float32(py)) / np.float32(gain)
+        best[:, [0, 2]] = best[:, [0, 2]].clip(0, W0)
+        best[:, [1, 3]] = best[:, [1, 3]].clip(0, H0)
+        best[~hit, :4] = 0
+        return best.astype(np.float32)
+
     def __call__(self, frame_bgr: np.ndarray, conf: float = 0.25):
         """Backend protocol of ``TemporalDetector``: → ``(xyxy [n,4] f32, conf [n] f32)``, n ∈ {0,1}: the
         top-confidence detection in ORIGINAL frame pixels (what detector.py:61-64 consumes)."""
-        H0, W0 = frame_bgr.shape[:2]
-        if frame_bgr.ndim == 2:
-            frame_bgr = np.repeat(frame_bgr[..., None], 3, axis=-1)
-        img, gain, px, py = letterbox_bgr(frame_bgr, self.imgsz)
-        b = self.detect_batch(img[None], conf)[0]
+        b = self.detect_frames(np.asarray(frame_bgr)[None], conf)[0]
         if b[4] < 0:
             return np.zeros((0, 4), np.float32), np.zeros(0, np.float32)
-        box = b[:4].copy()
-        if (gain, px, py) != (1.0, 0, 0):  # scale_boxes back to the original frame, then clip
-            box[[0, 2]] = (box[[0, 2]] - px) / gain
-            box[[1, 3]] = (box[[1, 3]] - py) / gain
-        box[[0, 2]] = box[[0, 2]].clip(0, W0)
-        box[[1, 3]] = box[[1, 3]].clip(0, H0)
-        return box[None].astype(np.float32), b[4:5].astype(np.float32)
+        return b[None, :4].astype(np.float32), b[4:5].astype(np.float32)
 
     def activation(self, name: str, B: int = 1) -> np.ndarray:
         dims = (C.c_int * 3)()

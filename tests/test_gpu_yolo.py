@@ -189,3 +189,47 @@ def test_cli_run_both_pipelines_end_to_end(tmp_path):
             ref = extract_features_unet(str(tmp_path / "video.npy"), det, m, "cuda:0")
             for k in ("area_mean", "area_std", "area_range", "open_quotient", "periodicity", "cv"):
                 assert got[k] == pytest.approx(float(ref[k]), rel=0, abs=0)
+
+
+@pytest.mark.parametrize("shape", [(512, 512), (128, 128), (224, 352), (256, 256), (250, 300)])
+def test_batched_and_per_frame_detector_paths_agree_on_any_frame_size(det, shape):
+    """`area_waveform` / `evaluate` batch the YOLO network; `TemporalDetector.detect` runs it per frame.  ultralytics
+    letterboxes every frame to the trained imgsz (256) and scales the boxes back, so both paths must do that — also
+    where the letterbox is not the identity (512x512 -> gain 0.5, 128x128 -> gain 2, 352x224 -> 256x192 + no pad,
+    300x250 -> padding)."""
+    from openglottal_amd import evaluate as E
+    from openglottal_amd.features import area_waveform
+    sd, d = det
+    H, W = shape
+    fr = frames(6, H, W, seed=H + W)
+    best = d.detect_frames(fr, 0.25)
+    td = og.TemporalDetector(d, conf=0.25)
+    per_frame = [td.detect(f) for f in fr]
+    td2 = og.TemporalDetector(lambda f, c: None)
+    batched = [td2.update(b[None, :4], b[4:5], W, H) if b[4] >= 0 else td2.update(None, None, W, H) for b in best]
+    assert per_frame == batched
+    for i, f in enumerate(fr):                      # raw boxes too, bit for bit (same letterbox, same scale-back)
+        xy, cf = d(f, 0.25)
+        assert (len(cf) == 0) == (best[i, 4] < 0)
+        if len(cf):
+            assert np.array_equal(xy[0], best[i, :4]) and cf[0] == best[i, 4]
+            assert 0 <= xy[0, 0] <= xy[0, 2] <= W and 0 <= xy[0, 1] <= xy[0, 3] <= H
+    # the two callers: gated area waveform and the eval harness give what the per-frame loop gives
+    feats = (4, 8, 16, 32)
+    m = og.UNet(1, 1, feats)
+    m.load_state_dict(synth.make_unet_state_dict(feats, seed=5, head_scale=3.0, head_bias=-0.4))
+    m.to("cuda:0").eval()
+    wave = area_waveform(list(fr), og.TemporalDetector(d), m)
+    td3 = og.TemporalDetector(d)
+    from openglottal_amd.utils import bgr_to_gray
+    for i, f in enumerate(fr):
+        b = td3.detect(f)
+        mk = og.unet_segment_frame(bgr_to_gray(f), m)
+        assert wave[i] == (0.0 if b is None else float(np.sum(mk[b[1]:b[3], b[0]:b[2]] > 0))), i
+    gts = np.zeros((6, H, W), np.uint8)
+    agg, _, st = E.evaluate(list(fr), gts, m, detector=og.TemporalDetector(d), reset_every_frame=True)
+    stateless = []
+    for f in fr:
+        t = og.TemporalDetector(d)
+        stateless.append(t.detect(f))
+    assert agg["yolo+unet"]["n_det"] == sum(b is not None for b in stateless)
