@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
 """Throughput bench of the U-Net-only glottal segmentation path on MI355X.
 
-Counterpart of the reference's scripts/benchmark_video_speed.py:89-109: a "step" is one
-pass of the frame loop (u8 gray frame -> /255 -> U-Net -> sigmoid -> >0.5 -> per-frame
-area) over `--frames` synthetic 256x256 frames per GPU that are already resident in HBM,
-followed by the area-waveform all-gather (RCCL) when N > 1.  Prints ONE JSON line.
+Counterpart of the reference's scripts/benchmark_video_speed.py:69-109.  Frames are the reference's synthetic frames,
+seeded as SURVEY 8(d) asks: frame i = RandomState(1234+i).randint(0,256,(256,256,3),uint8) BGR.  A "step" is one pass of
+the frame loop (BGR->gray, u8 -> /255 -> U-Net -> sigmoid -> >0.5 -> per-frame area) over this rank's frames, followed by
+the area-waveform all-gather (RCCL) when N > 1.  ONE JSON line:
 
-  python bench.py                       # 1 GPU
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+  value           frames/s with the (gray) frames already RESIDENT IN HBM when the timed region starts and the int32 areas
+                  left on the device (the contract's headline).
+  host_inclusive  the reference's timed region (benchmark_video_speed.py:83-109 / SURVEY 8(d)): pinned host BGR u8 frames
+                  -> H2D -> BGR->gray on the device -> U-Net -> int32 areas back on the host, through the streaming engine
+                  (og_unet_stream_u8); N = 1 only.
+  roofline        dominant kernel against the f32 MFMA peak, HIP events around every launch, live in this run.
+  cpu_baseline    the oracle's torch-CPU restatement of the same loop body on the host cores, 1 thread and all cores.
+
+  python bench.py                                   # 1 GPU, 512 frames per step
+  python bench.py --total-frames 10000              # C4's workload on however many ranks the launcher started (strong scaling)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -39,54 +48,81 @@ def host_cores() -> int:
     return n
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def kernel_source_sha() -> str:
+    """Identifies the device code a committed PMC measurement belongs to."""
+    h = hashlib.sha256()
+    for f in ("og_kernels.hpp", "og_api.hip"):
+        h.update(open(os.path.join(ROOT, "openglottal_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel: str, frames_per_launch: int):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*pmc_traffic*.json,
-    produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command)."""
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes (profiles/*pmc_traffic_chunkN.json,
+    tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs of this command).  Counters cannot be collected inside this
+    process; the entry therefore names its source file and says whether that file was measured on the device code that is
+    running now (`same_kernels`: sha of the kernel sources stored next to the numbers)."""
     import glob
 
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_traffic_chunk{frames_per_launch}.json"))):
-        best = path
-    if best is None:
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_traffic_chunk{frames_per_launch}.json")))
+    if not paths:
         return None
-    d = json.load(open(best))
+    d = json.load(open(paths[-1]))
     want = kernel.replace(",", ", ").replace(">", "")  # rocprof prints all template args, e.g. "<2, 0, 16, 2>"
     for name, v in d.items():
-        if want in name:
+        if isinstance(v, dict) and want in name:
             return {"hbm_bytes_per_launch": round(v["hbm_bytes_per_launch"]), "read": round(v["read_bytes_per_launch"]),
-                    "write": round(v["write_bytes_per_launch"]), "source": os.path.basename(best)}
+                    "write": round(v["write_bytes_per_launch"]), "source": os.path.basename(paths[-1]),
+                    "same_kernels": d.get("_kernel_source_sha") == kernel_source_sha()}
     return None
 
 
-def cpu_baseline(sd, budget_s: float = 12.0, max_frames: int = 256):
-    """Reference loop semantics (one frame per call, batch 1) on the host cores, timed on the
-    oracle's torch-CPU restatement (same oneDNN kernels the reference runs)."""
+def cpu_baseline(sd, budget_s: float = 10.0, max_frames: int = 256):
+    """Reference loop semantics (one frame per call, batch 1, BGR->gray included) on the host cores, timed on the oracle's
+    torch-CPU restatement (the same oneDNN kernels the reference runs), at 1 thread and at all cores."""
     import torch
 
     from oracle import unet_oracle as O
 
     from openglottal_amd import synth
+    from openglottal_amd.utils import bgr_to_gray
 
     sd_t = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
-    frames = synth.random_gray_frames(8, seed=3)
-    thr = host_cores()
-    torch.set_num_threads(thr)
+    frames = [synth.bench_frame_bgr(i) for i in range(8)]
 
     def one(f):
-        x = torch.from_numpy(f.astype("float32") / 255.0)[None, None]
+        g = bgr_to_gray(f)
+        x = torch.from_numpy(g.astype("float32") / 255.0)[None, None]
         with torch.no_grad():
             prob = torch.sigmoid(O.forward_torch(sd_t, x)).squeeze().numpy()
         return float(np.sum(((prob > 0.5).astype(np.uint8) * 255) > 0))
 
-    for i in range(3):
-        one(frames[i])
-    n, t0 = 0, time.perf_counter()
-    while n < max_frames and time.perf_counter() - t0 < budget_s:
-        one(frames[n % 8])
-        n += 1
-    el = time.perf_counter() - t0
-    return {"value": round(n / el, 2), "unit": "frames/s", "cores": int(thr), "kind": "port",
-            "sample": f"{n} frames 256x256, one frame per call (batch 1, fp32), oracle.forward_torch on {thr} host threads, {el:.1f} s"}
+    def run(threads, budget):
+        torch.set_num_threads(threads)
+        for i in range(2):
+            one(frames[i])
+        n, t0 = 0, time.perf_counter()
+        while n < max_frames and time.perf_counter() - t0 < budget:
+            one(frames[n % 8])
+            n += 1
+        return n, time.perf_counter() - t0
+
+    cores = host_cores()
+    n1, e1 = run(1, budget_s * 0.5)
+    na, ea = run(cores, budget_s)
+    return {"value": round(na / ea, 2), "unit": "frames/s", "cores": int(cores), "kind": "port",
+            "value_1_thread": round(n1 / e1, 2), "cpu_model": cpu_model(),
+            "sample": f"{na} frames at {cores} threads in {ea:.1f} s, {n1} frames at 1 thread in {e1:.1f} s; seeded 256x256 BGR frames, "
+                      "one frame per call (BGR->gray, /255, oracle.forward_torch fp32, sigmoid, >0.5, sum), as features.py:234-238"}
 
 
 def main() -> None:
@@ -94,7 +130,10 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=512, help="frames per GPU per step (weak scaling)")
+    ap.add_argument("--frames", type=int, default=512, help="frames per GPU per step (weak scaling; the default mode)")
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="> 0: ONE video of this many frames sharded over the ranks with shard_range (strong scaling; "
+                         "10000 = BASELINE config C4), last rank ragged")
     ap.add_argument("--chunk", type=int, default=64, help="frames per kernel chain (micro-batch of the frame loop)")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--lanes", type=int, default=2, choices=(1, 2),
@@ -105,6 +144,7 @@ def main() -> None:
                     help="og_unet_set_option knob for A/B measurements (results are bit-identical across them), repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-host-inclusive", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -112,7 +152,7 @@ def main() -> None:
 
     import openglottal_amd as og
     from openglottal_amd import synth
-    from openglottal_amd.dist import all_gather_areas, env_rank_world
+    from openglottal_amd.dist import all_gather_areas, env_rank_world, shard_range
 
     rank, local_rank, world = env_rank_world()
     if world != args.gpus and world > 1:
@@ -137,16 +177,32 @@ def main() -> None:
         k, v = kv.split("=")
         model.set_option(k, int(v))
 
-    F = args.frames
-    n_total = F * world
-    lo = rank * F
-    frames = torch.from_numpy(synth.bulk_gray_frames(F, seed=1234 + rank)).to(dev)  # resident in HBM before timing
-    area = torch.zeros(F, dtype=torch.int32, device=dev)
+    strong = args.total_frames > 0
+    if strong:
+        n_total = args.total_frames
+        lo, hi = shard_range(n_total, rank, world)
+    else:
+        n_total = args.frames * world
+        lo, hi = rank * args.frames, (rank + 1) * args.frames
+    F = hi - lo
+    # this rank's frames of the seeded stream (frame i = RandomState(1234+i), benchmark_video_speed.py:69 seeded), pinned
+    bgr_host = torch.empty((max(F, 1), 256, 256, 3), dtype=torch.uint8).pin_memory()
+    bh = bgr_host.numpy()
+    for j in range(F):
+        bh[j] = synth.bench_frame_bgr(lo + j)
+    bgr_dev = bgr_host[:F].to(dev)
+    frames = torch.empty((max(F, 1), 256, 256), dtype=torch.uint8, device=dev)   # gray, resident in HBM before timing
+    if F:
+        model.bgr2gray_dev(bgr_dev, F, 256, 256, frames)
+        model.sync()
+    del bgr_dev
+    area = torch.zeros(max(F, 1), dtype=torch.int32, device=dev)
 
     def step():
-        model.segment_dev(frames, F, 256, 256, area)
+        if F:
+            model.segment_dev(frames, F, 256, 256, area)
         model.sync()  # kernels run on the handle's stream; the collective on torch's
-        return all_gather_areas(area, n_total, force=force_dist) if (world > 1 or force_dist) else area
+        return all_gather_areas(area[:F], n_total, force=force_dist) if (world > 1 or force_dist) else area[:F]
 
     def fence():
         if world > 1 or force_dist:
@@ -171,21 +227,36 @@ def main() -> None:
     if rank == 0:
         fps = args.steps * n_total / el
         out = {
-            "metric": "frames/sec 256\u00d7256 U-Net-only", "value": round(fps, 1), "unit": "frames/s",
+            "metric": "frames/sec 256×256 U-Net-only (frames resident in HBM)", "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "U-Net-only 256x256 grayscale synthetic video, features (32,64,128,256), "
-                                   "frame loop u8->/255->UNet->sigmoid->>0.5->area, inputs resident in HBM",
-                       "frames_per_gpu_per_step": F, "frames_per_launch": args.chunk, "hip_graphs": not args.no_graphs,
-                       "lanes": args.lanes,
-                       "sharding": f"frames x{world}, all_gather(int32 area) per step" if world > 1 else "none",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "U-Net-only 256x256 grayscale synthetic video (BASELINE configs[1]; configs[3] with --total-frames 10000), "
+                                   "features (32,64,128,256), frames = RandomState(1234+i) BGR -> gray, frame loop u8->/255->UNet->sigmoid->>0.5->area, "
+                                   "gray frames resident in HBM, int32 areas left on the device",
+                       "frames_per_step_all_gpus": n_total, "frames_this_rank": F, "frames_per_launch": args.chunk,
+                       "hip_graphs": not args.no_graphs, "lanes": args.lanes,
+                       "sharding": (f"{'one video' if strong else 'frames'} x{world} (shard_range), all_gather(int32 area) per step" if world > 1 else "none"),
                        "flop_per_frame": model.flops_per_frame(256, 256)},
             "tflops": round(fps * model.flops_per_frame(256, 256) / 1e12, 2),
         }
         # whole-chain fractions (wall clock): binding roof = f32 MFMA; HBM with SURVEY 8(d)'s layer-boundary model
-        out["chain_frac_mfma"] = round(out["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
-        out["chain_frac_hbm_layer_boundary_model"] = round(fps * LAYER_BOUNDARY_BYTES_PER_FRAME / PEAK_HBM_BYTES, 4)
-    if world == 1 and not args.no_latency_mode:
+        out["chain_frac_mfma"] = round(out["tflops"] / PEAK_F32_MFMA_TFLOPS / world, 4)
+        out["chain_frac_hbm_layer_boundary_model"] = round(fps * LAYER_BOUNDARY_BYTES_PER_FRAME / PEAK_HBM_BYTES / world, 4)
+    if world == 1 and F and not args.no_host_inclusive:
+        # SURVEY 8(d) / benchmark_video_speed.py:83-109: first H2D enqueue -> last area on the host, BGR->gray inside
+        hf = bgr_host[:F]
+        model.segment_stream(hf[:min(F, 2 * args.chunk)])   # warm-up: ring allocation, graphs
+        reps = max(1, min(args.steps, 5))
+        fence(); t1 = time.perf_counter()
+        for _ in range(reps):
+            _, a_host = model.segment_stream(hf)
+        eh = time.perf_counter() - t1
+        assert np.array_equal(a_host, wave.cpu().numpy())       # same integers as the resident leg
+        out["host_inclusive"] = {"value": round(reps * F / eh, 1), "unit": "frames/s", "frames": F, "passes": reps,
+                                 "region": "pinned host BGR u8 [F,256,256,3] -> H2D -> BGR->gray (device) -> U-Net -> int32 areas on the host "
+                                           "(og_unet_stream_u8: ring of pinned micro-batches, copies under the kernel chains)",
+                                 "pcie_bytes_per_frame": 256 * 256 * 3 + 4}
+    if world == 1 and F and not args.no_latency_mode:
         # BASELINE configs[1] wording "batch=1": one frame per kernel chain, frames still resident in HBM
         n1 = min(F, 256)
         model.set_chunk(1)
@@ -195,7 +266,7 @@ def main() -> None:
         fence(); e1 = time.perf_counter() - t1
         out["latency_mode"] = {"frames_per_launch": 1, "value": round(n1 / e1, 1), "unit": "frames/s", "frames": n1}
         model.set_chunk(args.chunk)
-    if world == 1 and not args.no_roofline:
+    if world == 1 and F and not args.no_roofline:
         B = min(args.chunk, F)
         prof = model.profile(frames, B, 256, 256, reps=max(3, min(20, args.steps)))
         dom = [p for p in prof if p["kernel"] == DOMINANT]
@@ -204,10 +275,12 @@ def main() -> None:
         ach = fl / (ms * 1e-3) / 1e12
         tr = pmc_traffic(DOMINANT, B)   # HBM bytes per launch from the committed rocprofv3 PMC passes (or None)
         out["roofline"] = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": (tr or {}).get("hbm_bytes_per_launch"), "traffic_detail": tr,
+                           "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                           "traffic": (tr or {}).get("hbm_bytes_per_launch") if (tr or {}).get("same_kernels") else None,
+                           "traffic_detail": tr,
                            "launches_per_chain": len(dom), "avg_launch_ms": round(ms / len(dom), 4),
                            "share_of_chain_time": round(ms / tot_ms, 3), "frames_per_launch": B,
-                           "chain_ms": round(tot_ms, 3)}
+                           "chain_ms": round(tot_ms, 3), "kernel_source_sha": kernel_source_sha()}
         out["per_kernel_ms"] = {}
         for p in prof:
             out["per_kernel_ms"][p["kernel"]] = round(out["per_kernel_ms"].get(p["kernel"], 0.0) + p["ms"], 4)

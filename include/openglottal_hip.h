@@ -86,7 +86,15 @@ int og_unet_forward_f32(og_unet* h, const float* x_nchw, int B, int H, int W, fl
  * Host-pointer variant is synchronous (H2D, run, D2H). */
 int og_unet_segment_u8(og_unet* h, const uint8_t* gray, int B, int H, int W, float threshold,
                        const int32_t* boxes, uint8_t* mask, int32_t* area, float* logits);
-/* Same, DEVICE pointers, asynchronous on the handle's stream. */
+/* The frame loop of extract_features_unet with the video on the host (features.py:226,234-245), STREAMED: frames [B,H,W]
+ * gray (channels = 1) or [B,H,W,3] BGR (channels = 3; cv2.cvtColor(BGR2GRAY) of features.py:235 runs on the device) go up
+ * in micro-batches through a ring of pinned buffers, the copy of micro-batch k+1 and the return of micro-batch k-1 under the
+ * kernel chain of micro-batch k; device memory is bounded by (lanes + 2) micro-batches whatever B is (the reference loads
+ * every frame first, utils.py:43-54).  Pageable or pinned (hipHostMalloc / torch pin_memory) host memory; synchronous;
+ * boxes / mask / area as og_unet_segment_u8.  og_unet_segment_u8 itself runs on this engine (option "stream" 0: one-shot). */
+int og_unet_stream_u8(og_unet* h, const uint8_t* frames, int B, int H, int W, int channels, float threshold,
+                      const int32_t* boxes, uint8_t* mask, int32_t* area);
+/* Same as og_unet_segment_u8, DEVICE pointers, asynchronous on the handle's stream. */
 int og_unet_segment_u8_dev(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, float threshold,
                            const int32_t* boxes_dev, uint8_t* mask_dev, int32_t* area_dev, float* logits_dev);
 
@@ -101,7 +109,10 @@ int og_bgr2gray_dev(og_unet* h, const uint8_t* bgr_dev, int B, int H, int W, uin
  * crop boxes[b] from gray[b], letterbox it NEAREST into a size x size tile (zeros around), segment, project
  * the tile mask back NEAREST and paste it into a zero frame.  geom[b] = {pad_top, pad_left, content_h,
  * content_w} as `letterbox_with_info` returns them (host computes them: Python round()).  Boxes must be
- * inside the frame; x1 < 0 or an empty box gives an all-zero mask.  size must be a multiple of 2^n_levels. */
+ * inside the frame; x1 < 0 or an empty box gives an all-zero mask.  size must be a multiple of 2^n_levels.
+ * The host variant returns OG_EINVAL for a box that reaches outside the frame or a geom that does not fit the tile; the
+ * device variant cannot read them on the host, so its kernels treat such a record as "no detection" (all-zero mask)
+ * instead of indexing out of bounds. */
 int og_unet_segment_crops_u8(og_unet* h, const uint8_t* gray, int B, int H, int W, const int32_t* boxes, const int32_t* geom,
                              int size, float threshold, uint8_t* out_masks);
 int og_unet_segment_crops_u8_dev(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, const int32_t* boxes_dev,
@@ -122,7 +133,7 @@ int og_unet_set_graphs(og_unet* h, int enable);
  * "splitk_occ" 0|1 (K parts of a split launch on the occupancy kernel; 0: persistent kernel), "splitk_slots" 1..4 and "splitk_div" 1..8
  * (its target workgroups per CU / split when the launch fills less than 1/div of them),
  * "occ_min_pct" 0..400 (occupancy kernel when a launch has at least that many workgroups per 100 CUs), "convt_occ" 0|1, "fuse_first" 0|1 (first layer computed inside downs.0's second conv), "fuse_head" 0|1 (head +
- * threshold + area inside the last conv's epilogue), "keep_taps" 0|1, "dual" 0|1 (micro-batches of one call alternate over extra lanes = streams/arenas, so that launch tails overlap) with "lanes" 0..3 (0 = 3 lanes up to 16 frames per launch, else 2), and
+ * threshold + area inside the last conv's epilogue), "keep_taps" 0|1, "stream" 0|1 (og_unet_segment_u8 through the streaming engine, default 1; 0 = whole batch staged at once), "dual" 0|1 (micro-batches of one call alternate over extra lanes = streams/arenas, so that launch tails overlap) with "lanes" 0..3 (0 = 3 lanes up to 16 frames per launch, else 2), and
  * "splitk" 0|1 (1 = launches that would fill < 1/4 of the chip split K across workgroups; sums
  * are taken in a fixed order, so results are deterministic but differ in the last bits from the
  * unsplit order). */

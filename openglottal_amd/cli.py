@@ -1,8 +1,8 @@
 """``python -m openglottal_amd.cli run <video> --pipeline {unet,unet-only}``.
 
-Counterpart of the two U-Net branches of `openglottal/cli.py:46-103` (`_cmd_run`): same flags,
-same `features.json` payload (kinematic features without the private ``_area`` key, plus
-``pipeline``/``video``).  ``<video>`` may be a ``.npy``/``.npz`` frame stack (or an AVI when OpenCV
+Counterpart of the two U-Net branches of `openglottal/cli.py:46-103` (`_cmd_run`): same flags, same
+`features.json` payload (every key of the feature dict incl. the ``_area`` waveform as a list, `cli.py:97`), same
+messages; ``--annotate`` additionally records ``pipeline``/``video`` in the file.  ``<video>`` may be a ``.npy``/``.npz`` frame stack (or an AVI when OpenCV
 is importable); weights are a torch ``state_dict`` file (U-Net, `weights_only=True`) and a flat
 ``.npz`` export (YOLO, see yolo.py).
 """
@@ -24,6 +24,7 @@ def main(argv=None) -> int:
     r.add_argument("--yolo-weights", default=None)
     r.add_argument("--device", default="cuda")
     r.add_argument("-o", "--output", default="output")
+    r.add_argument("--annotate", action="store_true", help="also write the pipeline and video names into features.json")
     a = ap.parse_args(argv)
 
     import torch
@@ -38,15 +39,19 @@ def main(argv=None) -> int:
     detector = TemporalDetector(a.yolo_weights) if a.pipeline == "unet" else None
     feats = extract_features_unet(a.video, detector, model, a.device)
     if feats is None:
-        print("No features extracted (empty video or silent waveform).", file=sys.stderr)
+        print("No glottis detected — check your weights or input video.")
         return 1
     os.makedirs(a.output, exist_ok=True)
-    out = {k: (None if v is None else float(v)) for k, v in feats.items() if not k.startswith("_")}
-    out.update(pipeline=a.pipeline, video=str(a.video))
     path = os.path.join(a.output, "features.json")
+    save = {k: v.tolist() if hasattr(v, "tolist") else v for k, v in feats.items()}   # as cli.py:97: all keys, _area as a list
+    if a.annotate:
+        save.update(pipeline=a.pipeline, video=str(a.video))
     with open(path, "w") as f:
-        json.dump(out, f, indent=2)
+        json.dump(save, f, indent=2)
     print(f"Features saved to {path}")
+    for k, v in feats.items():
+        if not k.startswith("_"):
+            print(f"  {k}: {v:.4f}" if isinstance(v, float) else f"  {k}: {v}")
     return 0
 
 

@@ -1728,6 +1728,13 @@ __device__ __forceinline__ int og_nearest(int d, int src_len, int dst_len) {
     return s < src_len - 1 ? s : src_len - 1;
 }
 
+// A box / geometry record a kernel may index with: box inside the frame, content rectangle inside the tile.  Anything
+// else (a raw TemporalDetector box passed without clamping, a stale geom) yields zeros instead of an out-of-bounds access.
+__device__ __forceinline__ bool og_crop_ok(int x1, int y1, int x2, int y2, int top, int left, int ch, int cw, int H, int W, int size) {
+    return x1 >= 0 && y1 >= 0 && x2 > x1 && y2 > y1 && x2 <= W && y2 <= H && top >= 0 && left >= 0 && ch > 0 && cw > 0 &&
+           top + ch <= size && left + cw <= size;
+}
+
 __global__ __launch_bounds__(256) void k_crop_letterbox(const uint8_t* __restrict__ gray, int H, int W, const int32_t* __restrict__ boxes,
                                                         const int32_t* __restrict__ geom, int size, uint8_t* __restrict__ tiles) {
     const int b = blockIdx.y;
@@ -1738,7 +1745,7 @@ __global__ __launch_bounds__(256) void k_crop_letterbox(const uint8_t* __restric
     const int top = geom[b * 4], left = geom[b * 4 + 1], ch = geom[b * 4 + 2], cw = geom[b * 4 + 3];
     uint8_t v = 0;
     const int cy = ty - top, cx = tx - left;
-    if (x1 >= 0 && x2 > x1 && y2 > y1 && cy >= 0 && cy < ch && cx >= 0 && cx < cw) {
+    if (og_crop_ok(x1, y1, x2, y2, top, left, ch, cw, H, W, size) && cy >= 0 && cy < ch && cx >= 0 && cx < cw) {
         const int sy = og_nearest(cy, y2 - y1, ch), sx = og_nearest(cx, x2 - x1, cw);
         v = gray[((long long)b * H + y1 + sy) * W + x1 + sx];
     }
@@ -1754,7 +1761,7 @@ __global__ __launch_bounds__(256) void k_unletterbox_paste(const uint8_t* __rest
     const int x1 = boxes[b * 4], y1 = boxes[b * 4 + 1], x2 = boxes[b * 4 + 2], y2 = boxes[b * 4 + 3];
     const int top = geom[b * 4], left = geom[b * 4 + 1], ch = geom[b * 4 + 2], cw = geom[b * 4 + 3];
     uint8_t v = 0;
-    if (x1 >= 0 && x >= x1 && x < x2 && y >= y1 && y < y2) {
+    if (og_crop_ok(x1, y1, x2, y2, top, left, ch, cw, H, W, size) && x >= x1 && x < x2 && y >= y1 && y < y2) {
         const int hh = y2 - y1, ww = x2 - x1;
         const int sy = (ch == hh) ? (y - y1) : og_nearest(y - y1, ch, hh);
         const int sx = (cw == ww) ? (x - x1) : og_nearest(x - x1, cw, ww);

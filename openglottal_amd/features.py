@@ -85,57 +85,86 @@ def load_frames_bgr(source) -> list[np.ndarray]:
     return frames
 
 
-def area_waveform(frames, detector, model, device=None, threshold: float = 0.5) -> np.ndarray:
-    """The frame loop of features.py:234-245 as one batched device pass.
+BLOCK = 1024  # frames handed to the device engine per call (host side only: the engine itself streams micro-batches)
 
-    U-Net-only (``detector is None``): area = #(mask>0) per frame.  Gated: the
-    sequential TemporalDetector pass produces one box per frame first (the U-Net
-    does not depend on it), then the fused kernel counts inside the boxes.
+
+def iter_frame_blocks(source, block: int = BLOCK):
+    """Blocks ``[n<=block,H,W(,3)]`` of a video without loading it whole where the container allows it: an ``.npy`` file is
+    memory-mapped, an in-memory array is sliced (no copy), anything else goes through ``load_frames_bgr``."""
+    if isinstance(source, str) and source.endswith(".npy") and os.path.exists(source):
+        source = np.load(source, mmap_mode="r")
+    if isinstance(source, np.ndarray) and source.ndim >= 3:
+        for lo in range(0, len(source), block):
+            yield source[lo:lo + block]
+        return
+    frames = source if isinstance(source, (list, tuple)) else load_frames_bgr(source)
+    for lo in range(0, len(frames), block):
+        yield frames[lo:lo + block]
+
+
+def _detect_block(frames, detector) -> np.ndarray:
+    """Boxes ``[n,4]`` int32 for one block; the temporal state machine carries over from the previous block."""
+    n = len(frames)
+    boxes = np.empty((n, 4), np.int32)
+    batch = getattr(detector.model, "detect_frames", None)
+    shapes = {f.shape for f in frames}
+    if batch is not None and len(shapes) == 1:
+        # native backend, frames of one size: the YOLO network is per-frame independent, so run it batched on the device
+        # (letterboxed to the model's imgsz and scaled back exactly as the per-frame call does); only the O(1)/frame
+        # temporal state machine (detector.py:61-96) is sequential
+        best = batch(np.asarray(frames) if isinstance(frames, np.ndarray) else np.stack(frames), detector.conf)
+        H, W = frames[0].shape[:2]
+        for i in range(n):
+            b = detector.update(best[i:i + 1, :4], best[i:i + 1, 4], W, H) if best[i, 4] >= 0 else detector.update(None, None, W, H)
+            boxes[i] = normalize_box(b, W, H)
+    else:
+        for i, f in enumerate(frames):
+            b = detector.detect(f)
+            boxes[i] = normalize_box(b, f.shape[1], f.shape[0])
+    return boxes
+
+
+def area_waveform(frames, detector, model, device=None, threshold: float = 0.5) -> np.ndarray:
+    """The frame loop of features.py:234-245 as batched device passes over blocks of the video.
+
+    U-Net-only (``detector is None``): area = #(mask>0) per frame.  Gated: the sequential TemporalDetector pass produces
+    one box per frame first (the U-Net does not depend on it), then the fused kernel counts inside the boxes.  Frames at
+    network size go to the streaming engine as they are — BGR included: `cv2.cvtColor(BGR2GRAY)` (features.py:235) runs on
+    the device — so no per-frame host work is left and device memory does not grow with the video.
     """
     if device is not None and getattr(model, "_device", None) is None:
         model.to(device)
-    frames = list(frames)
-    n = len(frames)
-    if n == 0:
-        return np.zeros(0, np.float64)
-    shapes = {f.shape[:2] for f in frames}
-    boxes = None
     if detector is not None:
         detector.reset()
-        boxes = np.empty((n, 4), np.int32)
-        batch = getattr(detector.model, "detect_frames", None)
-        if batch is not None and len(shapes) == 1 and len({f.ndim for f in frames}) == 1:
-            # native backend, frames of one size: the YOLO network is per-frame independent, so run it batched on the
-            # device (letterboxed to the model's imgsz and scaled back exactly as the per-frame call does); only the
-            # O(1)/frame temporal state machine (detector.py:61-96) is sequential
-            best = batch(np.stack(frames), detector.conf)
-            H, W = frames[0].shape[:2]
-            for i in range(n):
-                b = detector.update(best[i:i + 1, :4], best[i:i + 1, 4], W, H) if best[i, 4] >= 0 else detector.update(None, None, W, H)
-                boxes[i] = normalize_box(b, W, H)
-        else:
-            for i, f in enumerate(frames):
-                b = detector.detect(f)
-                boxes[i] = normalize_box(b, f.shape[1], f.shape[0])
-    if shapes == {(NET_SIZE, NET_SIZE)}:
-        gray = np.stack([bgr_to_gray(f) for f in frames])
-        _, area, _ = model.segment(gray, threshold=threshold, boxes=boxes, want_mask=False)
-        return area.astype(np.float64)
-    out = np.zeros(n, np.float64)  # mixed / non-256 frames: per-frame path incl. host resizes
-    for i, f in enumerate(frames):
-        m = unet_segment_frame(bgr_to_gray(f), model, device, threshold)
-        if boxes is None:
-            out[i] = float(np.sum(m > 0))
-        elif boxes[i][0] >= 0:
-            x1, y1, x2, y2 = boxes[i]
-            out[i] = float(np.sum(m[y1:y2, x1:x2] > 0))
-    return out
+    out = []
+    done = 0
+    for blk in iter_frame_blocks(frames):
+        n = len(blk)
+        if n == 0:
+            continue
+        boxes = _detect_block(blk, detector) if detector is not None else None
+        shapes = {f.shape for f in blk}
+        if len(shapes) == 1 and next(iter(shapes))[:2] == (NET_SIZE, NET_SIZE):
+            arr = blk if isinstance(blk, np.ndarray) else np.stack(blk)
+            _, area = model.segment_stream(arr, threshold=threshold, boxes=boxes)
+            out.append(area.astype(np.float64))
+        else:   # mixed / non-256 frames: per-frame path incl. host resizes (utils.py:234,239-240)
+            a = np.zeros(n, np.float64)
+            for i, f in enumerate(blk):
+                m = unet_segment_frame(bgr_to_gray(f), model, device, threshold)
+                if boxes is None:
+                    a[i] = float(np.sum(m > 0))
+                elif boxes[i][0] >= 0:
+                    x1, y1, x2, y2 = boxes[i]
+                    a[i] = float(np.sum(m[y1:y2, x1:x2] > 0))
+            out.append(a)
+        done += n
+    return np.concatenate(out) if out else np.zeros(0, np.float64)
 
 
 def extract_features_unet(avi_path, detector, model, device=None) -> dict | None:
     """Drop-in for `openglottal/features.py:202-247` (U-Net-only when ``detector is None``)."""
-    frames = load_frames_bgr(avi_path)
-    if not frames:
-        return None
-    wave = area_waveform(frames, detector, model, device)
+    wave = area_waveform(avi_path, detector, model, device)
+    if len(wave) == 0:
+        return None   # features.py:227-228
     return _kinematic_features([float(v) for v in wave])

@@ -131,6 +131,32 @@ class UNet:
                                        ptr(logits)), "og_unet_segment_u8")
         return mask, area, logits
 
+    def segment_stream(self, frames, threshold: float = 0.5, boxes=None, want_mask: bool = False):
+        """The frame loop over host frames through the streaming ingest engine (``og_unet_stream_u8``): ``[B,H,W]`` gray or
+        ``[B,H,W,3]`` BGR u8 (BGR→gray of features.py:235 on the device), numpy or a pinned torch tensor.  Device memory
+        stays bounded by a few micro-batches however long the video is.  Returns ``(mask | None, area int32 [B])``."""
+        self._require()
+        if hasattr(frames, "data_ptr"):          # torch CPU tensor (pinned or not): use its memory in place
+            if frames.device.type != "cpu" or str(frames.dtype) != "torch.uint8" or not frames.is_contiguous():
+                raise OpenGlottalHipError("segment_stream expects a contiguous uint8 host tensor")
+            f, shape = frames, tuple(frames.shape)
+        else:
+            f = np.ascontiguousarray(frames, dtype=np.uint8)
+            shape = f.shape
+        if len(shape) == 4 and shape[-1] == 3:
+            ch = 3
+        elif len(shape) == 3:
+            ch = 1
+        else:
+            raise OpenGlottalHipError(f"expected [B,H,W] or [B,H,W,3] frames, got {shape}")
+        B, H, W = shape[:3]
+        mask = np.empty((B, H, W), np.uint8) if want_mask else None
+        area = np.zeros(B, np.int32)
+        bx = None if boxes is None else np.ascontiguousarray(boxes, dtype=np.int32).reshape(B, 4)
+        check(lib().og_unet_stream_u8(self._h, ptr(f), B, H, W, ch, float(threshold), ptr(bx), ptr(mask), ptr(area)),
+              "og_unet_stream_u8")
+        return mask, area
+
     def segment_dev(self, gray_dev, B: int, H: int, W: int, area_dev, threshold: float = 0.5, boxes_dev=None,
                     mask_dev=None, logits_dev=None) -> None:
         """Device-pointer, asynchronous variant (torch CUDA tensors or raw ints)."""

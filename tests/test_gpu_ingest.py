@@ -95,3 +95,112 @@ def test_mask_area_dev_equals_numpy_slices_and_golden_gated(trained, golden_dir)
     m.mask_area_dev(torch.from_numpy(mk).to(dev), 3, 40, 72, torch.from_numpy(bx).to(dev), out3)
     m.sync()
     assert out3.cpu().tolist() == [int((mk[0][3:33, 5:60] > 0).sum()), int((mk[1] > 0).sum()), 0]
+
+
+def test_crop_entry_points_refuse_or_neutralise_out_of_frame_boxes(trained):
+    """A ctypes caller may hand raw TemporalDetector boxes (not clamped) to the crop entry points: the host variant must
+    refuse them (OG_EINVAL), the device variant must not index out of bounds (such a record counts as "no detection")."""
+    import torch
+
+    from openglottal_amd._lib import check, lib, ptr
+
+    g, m, frames = trained
+    fr = np.ascontiguousarray(frames[:4])
+    boxes = np.array([[10, 10, 100, 120], [200, 200, 300, 260], [-5, 10, 50, 60], [0, 0, 256, 256]], np.int32)   # 1: outside; 2: "none"
+    geom = np.array([[0, 23, 256, 209], [0, 0, 256, 256], [0, 0, 256, 256], [0, 0, 256, 256]], np.int32)
+    out = np.empty_like(fr)
+    rc = lib().og_unet_segment_crops_u8(m._h, ptr(fr), 4, 256, 256, ptr(boxes), ptr(geom), 256, 0.5, ptr(out))
+    assert rc == -1 and "outside the frame" in lib().og_last_error().decode()
+    bad_geom = geom.copy(); bad_geom[0] = [200, 0, 100, 256]     # top + content_h > size
+    ok_boxes = boxes.copy(); ok_boxes[1] = [200, 200, 256, 256]
+    rc = lib().og_unet_segment_crops_u8(m._h, ptr(fr), 4, 256, 256, ptr(ok_boxes), ptr(bad_geom), 256, 0.5, ptr(out))
+    assert rc == -1 and "does not fit" in lib().og_last_error().decode()
+    # device variant with the same bad records: runs, and the bad frames come back all-zero
+    dev = torch.device("cuda", 0)
+    d = {k: torch.from_numpy(v).to(dev) for k, v in dict(fr=fr, boxes=boxes, geom=bad_geom).items()}
+    tiles = torch.zeros((4, 256, 256), dtype=torch.uint8, device=dev)
+    tmask = torch.zeros_like(tiles)
+    outd = torch.full((4, 256, 256), 7, dtype=torch.uint8, device=dev)
+    check(lib().og_unet_segment_crops_u8_dev(m._h, ptr(d["fr"]), 4, 256, 256, ptr(d["boxes"]), ptr(d["geom"]), 256, 0.5,
+                                             ptr(tiles), ptr(tmask), ptr(outd)), "crops_dev")
+    m.sync()
+    o = outd.cpu().numpy()
+    assert not o[0].any() and not o[1].any() and not o[2].any()          # bad geom / outside the frame / no detection
+    full, _, _ = m.segment(fr[3:4])
+    assert np.array_equal(o[3], full[0])                                  # the valid record is untouched by its neighbours
+
+
+def test_streaming_engine_equals_one_shot_staging(trained):
+    """og_unet_segment_u8 on the streaming engine (pinned ring, chunked async H2D / D2H under the kernel chains) must give
+    bit for bit what staging the whole batch at once gives: masks, areas, logits, with and without boxes, ragged batch."""
+    g, m, frames = trained
+    idx = np.arange(203) % 80
+    fr = np.ascontiguousarray(frames[idx])
+    rs = np.random.RandomState(5)
+    boxes = np.array([normalize_box((int(x), int(y), int(x + 60), int(y + 90)), 256, 256) for x, y in rs.randint(0, 200, (203, 2))], np.int32)
+    boxes[7] = -1
+    try:
+        for chunk in (16, 64, 7):
+            m.set_chunk(chunk)
+            m.set_option("stream", 0)
+            mk0, ar0, lg0 = m.segment(fr, want_logits=True)
+            _, arb0, _ = m.segment(fr, boxes=boxes, want_mask=False)
+            m.set_option("stream", 1)
+            mk1, ar1, lg1 = m.segment(fr, want_logits=True)
+            _, arb1, _ = m.segment(fr, boxes=boxes, want_mask=False)
+            assert np.array_equal(mk0, mk1) and np.array_equal(ar0, ar1) and np.array_equal(lg0, lg1), chunk
+            assert np.array_equal(arb0, arb1) and arb1[7] == 0, chunk
+            assert np.array_equal(ar1.astype(np.int64), g["areas"][idx])       # and both equal the reference's integers
+            mk2, ar2 = m.segment_stream(fr, want_mask=True)
+            assert np.array_equal(mk2, mk1) and np.array_equal(ar2, ar1)
+    finally:
+        m.set_chunk(32)
+        m.set_option("stream", 1)
+
+
+def test_streaming_bgr_frames_pinned_and_pageable(trained):
+    """BGR frames go up once and `k_bgr2gray` feeds the chain (features.py:235 on the device): equals host BGR->gray +
+    gray segmentation; a pinned torch tensor (DMA straight from it) equals pageable numpy memory."""
+    import torch
+
+    g, m, frames = trained
+    rs = np.random.RandomState(3)
+    bgr = np.clip(frames[:70, ..., None].astype(np.int32) + rs.randint(-30, 30, (70, 256, 256, 3)), 0, 255).astype(np.uint8)
+    gray = bgr_to_gray(bgr)
+    m.set_chunk(16)
+    try:
+        mk_ref, ar_ref, _ = m.segment(gray)
+        mk, ar = m.segment_stream(bgr, want_mask=True)
+        assert np.array_equal(mk, mk_ref) and np.array_equal(ar, ar_ref)
+        pinned = torch.from_numpy(bgr).pin_memory()
+        assert pinned.is_pinned()
+        mk_p, ar_p = m.segment_stream(pinned, want_mask=True)
+        assert np.array_equal(mk_p, mk_ref) and np.array_equal(ar_p, ar_ref)
+        # the callers: extract_features_unet / area_waveform on a BGR video use the device conversion
+        from openglottal_amd.features import area_waveform
+        assert np.array_equal(area_waveform(bgr, None, m), ar_ref.astype(np.float64))
+        assert np.array_equal(area_waveform(list(bgr), None, m), ar_ref.astype(np.float64))
+    finally:
+        m.set_chunk(32)
+
+
+def test_streaming_keeps_device_memory_bounded_for_a_long_video(trained, tmp_path):
+    """A 6 000-frame video (memory-mapped .npy, 393 MB of frames) through extract_features_unet: device memory in use
+    grows by the ring and one arena per lane, not by the video; the waveform repeats the golden integers."""
+    import torch
+
+    from openglottal_amd.features import area_waveform
+
+    g, m, frames = trained
+    idx = np.arange(6000) % 80
+    path = str(tmp_path / "long.npy")
+    np.save(path, frames[idx])
+    m.set_chunk(32)
+    area_waveform(frames[:64], None, m)            # ring + arenas exist now
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    wave = area_waveform(path, None, m)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert np.array_equal(wave.astype(np.int64), g["areas"][idx])
+    assert free0 - free1 < 64 << 20, (free0, free1)   # nothing proportional to 6 000 frames (393 MB) was allocated

@@ -5,6 +5,8 @@ these tests prove the HIP implementation and the independent torch restatement a
 layer, and that TemporalDetector over the native backend behaves like the scripted reference runs.
 Tolerance: activations abs <= 2e-4 * max(1,|ref|max) (fp32, ~60 layers deep, SiLU); boxes <= 2e-2 px; conf <= 1e-4.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -183,12 +185,21 @@ def test_cli_run_both_pipelines_end_to_end(tmp_path):
         assert rc in (0, 1)
         if rc == 0:
             got = json.load(open(out / "features.json"))
-            assert got["pipeline"] == pipe and {"area_mean", "area_std", "area_range", "open_quotient", "f0", "periodicity", "cv"} <= set(got)
+            # exactly the reference's payload (cli.py:97 dumps every key of the feature dict, `_area` as a list): the key
+            # set of the reference-generated kinematic fixture + `_area`
+            ref_keys = set(json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kinematic.json")))["periodic"]["out"])
+            assert set(got) == ref_keys | {"_area"}, set(got) ^ (ref_keys | {"_area"})
+            assert isinstance(got["_area"], list) and len(got["_area"]) == 24
             m = og.UNet(1, 1, feats); m.load_state_dict(sd); m.to("cuda:0").eval()
             det = og.TemporalDetector(str(tmp_path / "yolo.npz")) if pipe == "unet" else None
             ref = extract_features_unet(str(tmp_path / "video.npy"), det, m, "cuda:0")
             for k in ("area_mean", "area_std", "area_range", "open_quotient", "periodicity", "cv"):
                 assert got[k] == pytest.approx(float(ref[k]), rel=0, abs=0)
+            assert got["_area"] == ref["_area"].tolist()
+    rc = cli.main(["run", str(tmp_path / "video.npy"), "--pipeline", "unet-only", "--unet-weights", str(tmp_path / "unet.pt"),
+                   "--device", "cuda:0", "-o", str(tmp_path / "ann"), "--annotate"])
+    if rc == 0:
+        assert json.load(open(tmp_path / "ann" / "features.json"))["pipeline"] == "unet-only"
 
 
 @pytest.mark.parametrize("shape", [(512, 512), (128, 128), (224, 352), (256, 256), (250, 300)])
