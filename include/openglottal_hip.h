@@ -119,6 +119,23 @@ int og_unet_segment_crops_u8_dev(og_unet* h, const uint8_t* gray_dev, int B, int
                                  const int32_t* geom_dev, int size, float threshold, uint8_t* tiles_scratch_dev,
                                  uint8_t* tile_masks_scratch_dev, uint8_t* out_masks_dev);
 
+/* BAGLS front end (scripts/eval_bagls.py:46-70,153-155 `letterbox`): frames of mixed sizes, packed back to back in one
+ * buffer (frame b = shapes[b] = {H, W} pixels of `channels` bytes starting at byte offsets[b]), are scaled so that the
+ * longest side equals `size` and padded symmetrically with `value`: INTER_NEAREST for channels = 1 (gray frames, GT masks),
+ * INTER_LINEAR for channels = 3 (BGR), as the reference's letterbox chooses.  geom[b] = {pad_top, pad_left, content_h,
+ * content_w} as the host computes them (Python round()).  out [B,size,size,channels].  OpenCV's index / coefficient rules
+ * as restated in openglottal_amd/geometry.py (parity unpinned: cv2 is absent). */
+int og_canvas_letterbox_u8(og_unet* h, const uint8_t* packed, const int64_t* offsets, const int32_t* shapes, int B, int channels,
+                           int size, const int32_t* geom, int value, uint8_t* out);
+int og_canvas_letterbox_u8_dev(og_unet* h, const uint8_t* packed_dev, const int64_t* offsets_dev, const int32_t* shapes_dev, int B,
+                               int channels, int size, const int32_t* geom_dev, int value, uint8_t* out_dev);
+
+/* Per-frame confusion counts for `frame_metrics` (scripts/eval_bagls.py:75-87, eval_girafe.py:113-124) on resident masks:
+ * stats[b] = {tp, n_pred, n_gt} int32 (fp = n_pred - tp, fn = n_gt - tp).  boxes (or NULL): the prediction counts only
+ * inside the box, x1 < 0 = empty prediction -- the "yolo+unet" row (eval_bagls.py:201-207). */
+int og_mask_stats_dev(og_unet* h, const uint8_t* pred_dev, const uint8_t* gt_dev, int B, int H, int W, const int32_t* boxes_dev,
+                      int32_t* stats_dev);
+
 int og_unet_sync(og_unet* h);
 void* og_unet_stream(og_unet* h);          /* hipStream_t the handle launches on */
 

@@ -49,6 +49,11 @@ PROTOTYPES = {
                                            C.c_float, C.c_void_p]),
     "og_unet_segment_crops_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "og_canvas_letterbox_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                         C.c_void_p]),
+    "og_canvas_letterbox_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_int, C.c_void_p]),
+    "og_mask_stats_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "og_mask_area_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "og_bgr2gray_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "og_unet_sync": (C.c_int, [C.c_void_p]),

@@ -1541,6 +1541,69 @@ int og_bgr2gray_dev(og_unet* h, const uint8_t* bgr, int B, int H, int W, uint8_t
     return OG_OK;
 }
 
+int og_canvas_letterbox_u8_dev(og_unet* h, const uint8_t* packed, const int64_t* offsets, const int32_t* shapes, int B, int channels,
+                               int size, const int32_t* geom, int value, uint8_t* out) {
+    if (!h || !h->finalized) return fail(OG_ESTATE, "handle not finalized");
+    if (B < 0 || size <= 0 || (channels != 1 && channels != 3) || value < 0 || value > 255) return fail(OG_EINVAL, "bad argument");
+    if (B == 0) return OG_OK;
+    if (!packed || !offsets || !shapes || !geom || !out) return fail(OG_EINVAL, "null buffer");
+    const size_t SS = (size_t)size * size * channels;
+    for (int b0 = 0; b0 < B; b0 += 65535) {   // grid.y <= 65535
+        const int nb = (B - b0 < 65535) ? B - b0 : 65535;
+        const dim3 grid((size * size + 255) / 256, nb);
+        if (channels == 1)
+            hipLaunchKernelGGL(k_canvas_letterbox<1>, grid, dim3(256), 0, h->stream, packed, (const long long*)offsets + b0, shapes + 2 * b0,
+                               geom + 4 * b0, size, value, out + b0 * SS);
+        else
+            hipLaunchKernelGGL(k_canvas_letterbox<3>, grid, dim3(256), 0, h->stream, packed, (const long long*)offsets + b0, shapes + 2 * b0,
+                               geom + 4 * b0, size, value, out + b0 * SS);
+        HIPCHK(hipGetLastError());
+    }
+    return OG_OK;
+}
+
+int og_canvas_letterbox_u8(og_unet* h, const uint8_t* packed, const int64_t* offsets, const int32_t* shapes, int B, int channels, int size,
+                           const int32_t* geom, int value, uint8_t* out) {
+    if (!h || !h->finalized) return fail(OG_ESTATE, "handle not finalized");
+    if (B < 0 || size <= 0 || (channels != 1 && channels != 3)) return fail(OG_EINVAL, "bad argument");
+    if (B == 0) return OG_OK;
+    if (!packed || !offsets || !shapes || !geom || !out) return fail(OG_EINVAL, "null buffer");
+    size_t total = 0;
+    for (int b = 0; b < B; ++b) {   // host variant: the records are readable here, so check them
+        const long long hh = shapes[2 * b], ww = shapes[2 * b + 1];
+        if (hh <= 0 || ww <= 0 || offsets[b] < 0) return fail(OG_EINVAL, "bad frame record " + std::to_string(b));
+        const size_t end = (size_t)offsets[b] + (size_t)hh * ww * channels;
+        if (end > total) total = end;
+    }
+    const size_t SS = (size_t)size * size * channels;
+    const size_t o_pk = 0, o_off = al256(total), o_shp = o_off + al256((size_t)B * 8), o_geo = o_shp + al256((size_t)B * 8),
+                 o_out = o_geo + al256((size_t)B * 16), tot = o_out + al256(B * SS);
+    int rc;
+    if ((rc = ensure_stage(h, tot))) return rc;
+    char* s = (char*)h->stage;
+    HIPCHK(hipMemcpyAsync(s + o_pk, packed, total, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(s + o_off, offsets, (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(s + o_shp, shapes, (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(s + o_geo, geom, (size_t)B * 16, hipMemcpyHostToDevice, h->stream));
+    if ((rc = og_canvas_letterbox_u8_dev(h, (const uint8_t*)(s + o_pk), (const int64_t*)(s + o_off), (const int32_t*)(s + o_shp), B, channels,
+                                         size, (const int32_t*)(s + o_geo), value, (uint8_t*)(s + o_out))))
+        return rc;
+    HIPCHK(hipMemcpyAsync(out, s + o_out, B * SS, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return OG_OK;
+}
+
+int og_mask_stats_dev(og_unet* h, const uint8_t* pred, const uint8_t* gt, int B, int H, int W, const int32_t* boxes, int32_t* stats) {
+    if (!h || !h->finalized) return fail(OG_ESTATE, "handle not finalized");
+    if (!pred || !gt || !stats || B < 0 || H <= 0 || W <= 0) return fail(OG_EINVAL, "bad argument");
+    if (B == 0) return OG_OK;
+    HIPCHK(hipMemsetAsync(stats, 0, (size_t)B * 12, h->stream));
+    const int HW = H * W, bpf = (HW + 4095) / 4096;
+    hipLaunchKernelGGL(k_mask_stats, dim3(B * bpf), dim3(256), 0, h->stream, pred, gt, HW, W, boxes, stats, bpf);
+    HIPCHK(hipGetLastError());
+    return OG_OK;
+}
+
 int og_unet_segment_crops_u8_dev(og_unet* h, const uint8_t* gray, int B, int H, int W, const int32_t* boxes, const int32_t* geom,
                                  int size, float thr, uint8_t* tiles_scratch, uint8_t* tile_masks_scratch, uint8_t* out_masks) {
     int rc = check_shape(h, B, size, size);

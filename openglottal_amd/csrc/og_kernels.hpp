@@ -1769,3 +1769,97 @@ __global__ __launch_bounds__(256) void k_unletterbox_paste(const uint8_t* __rest
     }
     out[(long long)b * H * W + p] = v;
 }
+
+// =======================================================================================
+// BAGLS front end on the device (scripts/eval_bagls.py:46-70,153-155): frames and GT masks of mixed sizes are scaled so
+// that the longest side equals `size` and padded symmetrically (letterbox).  2-D arrays (gray frames, masks) are
+// resampled INTER_NEAREST, BGR frames INTER_LINEAR, as the reference does (eval_bagls.py:57).  Index / coefficient rules
+// = OpenCV's as restated in openglottal_amd/geometry.py (resize_nearest / resize_linear, u8 path: half-pixel centres,
+// 11-bit coefficients, ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2): the two are compared pixel for pixel.
+// Frames are packed back to back in one buffer; frame b starts at offsets[b] and is shapes[b] = {H, W}.
+// geom[b] = {pad_top, pad_left, content_h, content_w} (host: Python round()).
+// =======================================================================================
+__device__ __forceinline__ void og_linear_tap(int d, int src_len, int dst_len, int& i0, int& i1, int& a0, int& a1) {
+    const double f = ((double)d + 0.5) * ((double)src_len / (double)dst_len) - 0.5;
+    int k = (int)floor(f);
+    float frac = (float)(f - (double)k);
+    if (k < 0) { k = 0; frac = 0.f; }
+    if (k >= src_len - 1) { k = src_len - 1; frac = 0.f; }
+    i0 = k;
+    i1 = (k + 1 < src_len) ? k + 1 : src_len - 1;
+    a1 = (int)rintf(frac * 2048.0f);
+    a0 = 2048 - a1;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_canvas_letterbox(const uint8_t* __restrict__ packed, const long long* __restrict__ offsets,
+                                                          const int32_t* __restrict__ shapes, const int32_t* __restrict__ geom, int size,
+                                                          int value, uint8_t* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= size * size) return;
+    const int ty = t / size, tx = t - ty * size;
+    const int H = shapes[b * 2], W = shapes[b * 2 + 1];
+    const int top = geom[b * 4], left = geom[b * 4 + 1], ch = geom[b * 4 + 2], cw = geom[b * 4 + 3];
+    const uint8_t* src = packed + offsets[b];
+    uint8_t* o = out + ((long long)b * size * size + t) * C;
+    const int cy = ty - top, cx = tx - left;
+    const bool ok = H > 0 && W > 0 && ch > 0 && cw > 0 && top >= 0 && left >= 0 && top + ch <= size && left + cw <= size;
+    if (!ok || cy < 0 || cy >= ch || cx < 0 || cx >= cw) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[c] = (uint8_t)value;
+        return;
+    }
+    if (C == 1) {
+        const int sy = og_nearest(cy, H, ch), sx = og_nearest(cx, W, cw);
+        o[0] = src[(long long)sy * W + sx];
+    } else {
+        int x0, x1, ax0, ax1, y0, y1, ay0, ay1;
+        og_linear_tap(cx, W, cw, x0, x1, ax0, ax1);
+        og_linear_tap(cy, H, ch, y0, y1, ay0, ay1);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int r0 = (int)src[((long long)y0 * W + x0) * C + c] * ax0 + (int)src[((long long)y0 * W + x1) * C + c] * ax1;
+            const int r1 = (int)src[((long long)y1 * W + x0) * C + c] * ax0 + (int)src[((long long)y1 * W + x1) * C + c] * ax1;
+            int v = (((ay0 * (r0 >> 4)) >> 16) + ((ay1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            o[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+
+// Per-frame confusion counts of a predicted mask against a ground-truth mask (scripts/eval_bagls.py:75-87 `frame_metrics`
+// needs tp, fp, fn): stats[b] = {tp, n_pred, n_gt}.  With boxes, the prediction counts only inside the box -- the
+// "yolo+unet" row zeroes the mask outside it (eval_bagls.py:201-207); x1 < 0 = no detection = empty prediction.
+__global__ __launch_bounds__(256) void k_mask_stats(const uint8_t* __restrict__ pred, const uint8_t* __restrict__ gt, int HW, int W,
+                                                    const int32_t* __restrict__ boxes, int32_t* __restrict__ stats, int blocks_per_frame) {
+    const int b = blockIdx.x / blocks_per_frame;
+    const int blk = blockIdx.x - b * blocks_per_frame;
+    int bx1 = 0, by1 = 0, bx2 = 1 << 30, by2 = 1 << 30;
+    if (boxes != nullptr) {
+        bx1 = boxes[b * 4 + 0];
+        by1 = boxes[b * 4 + 1];
+        bx2 = boxes[b * 4 + 2];
+        by2 = boxes[b * 4 + 3];
+        if (bx1 < 0) { bx2 = 0; by2 = 0; bx1 = 0; by1 = 0; }
+    }
+    int tp = 0, np_ = 0, ng = 0;
+    for (int p = blk * 4096 + threadIdx.x; p < min(HW, (blk + 1) * 4096); p += 256) {
+        const int y = p / W, x = p - y * W;
+        const bool pr = pred[(long long)b * HW + p] > 0 && x >= bx1 && x < bx2 && y >= by1 && y < by2;
+        const bool g = gt[(long long)b * HW + p] > 0;
+        tp += (pr && g) ? 1 : 0;
+        np_ += pr ? 1 : 0;
+        ng += g ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        tp += __shfl_down(tp, o);
+        np_ += __shfl_down(np_, o);
+        ng += __shfl_down(ng, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (tp) atomicAdd(&stats[b * 3 + 0], tp);
+        if (np_) atomicAdd(&stats[b * 3 + 1], np_);
+        if (ng) atomicAdd(&stats[b * 3 + 2], ng);
+    }
+}

@@ -13,6 +13,7 @@ decoding is host I/O behind cv2 and stays with the caller.
 from __future__ import annotations
 
 import json
+import os
 from collections import defaultdict
 
 import numpy as np
@@ -174,8 +175,174 @@ def print_table(agg) -> None:
     print(sep)
 
 
-def dump_json(path: str, agg, det_stats=None) -> None:
-    """Per-frame lists + summary, the shape of `results/bagls_eval.json` (eval_bagls.py:369-391)."""
+def dump_json(path: str, agg, det_stats=None, meta=None) -> None:
+    """Per-frame metrics in the shape of the reference's `results/bagls_eval.json` (eval_bagls.py:369-391): one entry per
+    pipeline with ``dice`` / ``iou`` lists and the ``n_det`` / ``n_total`` counters, plus ``_meta``."""
+    from datetime import datetime
+
+    out = {p: {k: (v if isinstance(v, (int, float)) else [float(x) for x in v]) for k, v in d.items()} for p, d in agg.items()}
+    out["_meta"] = dict({"crop_letterbox": True, "written_at": datetime.now().isoformat()}, **(meta or {}))
+    if det_stats is not None:
+        out["_meta"]["det_stats"] = {k: int(v) for k, v in det_stats.items()}
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as f:
-        json.dump({"summary": summarize(agg), "per_frame": {p: {"dice": d["dice"], "iou": d["iou"]} for p, d in agg.items()},
-                   "det_stats": det_stats}, f, indent=1)
+        json.dump(out, f, indent=2)
+
+
+# ── C5 on the device: BAGLS front end + three pipelines + metrics without a mask leaving HBM ───────────────────
+
+
+def metrics_from_counts(tp, n_pred, n_gt) -> tuple[float, float]:
+    """`frame_metrics` (eval_bagls.py:75-87) from integer confusion counts, in the reference's float32 arithmetic."""
+    tp_, fp, fn = np.float32(tp), np.float32(n_pred - tp), np.float32(n_gt - tp)
+    d_den, i_den = 2 * tp_ + fp + fn, tp_ + fp + fn
+    return (float(2 * tp_ / d_den) if d_den > 0 else 1.0, float(tp_ / i_den) if i_den > 0 else 1.0)
+
+
+def evaluate_counts_device(frames, gts, unet_model, detector=None, crop_model=None, canvas: int = NET_SIZE, crop_pad: int = 0,
+                           block: int = 512) -> np.ndarray:
+    """The BAGLS evaluation loop (eval_bagls.py:120-232) for frames of MIXED sizes, entirely on the device, returning per
+    frame ``[tp_u, np_u, ng, tp_yu, np_yu, tp_c, np_c, detected, det_tp, gt_pos]`` (int64 ``[N,10]``): the canvas letterbox of
+    frame and GT (``k_canvas_letterbox``), BGR→gray, the stateless detector pass (`detector.reset()` before every frame,
+    eval_bagls.py:164-166), the full-frame U-Net, the box-gated row, the crop → 256² → project-back row and the confusion
+    counts all stay in HBM; 40 bytes per frame come back.  Frames are independent, so the rows of different shards can
+    simply be concatenated (`dist.sharded_eval_counts`)."""
+    import torch
+
+    from ._lib import check, lib, ptr
+    from .geometry import letterbox_geometry, pack_frames
+    from .utils import normalize_box
+
+    n = len(frames)
+    out = np.zeros((n, 10), np.int64)
+    if n == 0:
+        return out
+    unet_model._require()
+    dev = torch.device("cuda", unet_model._device or 0)
+    S = int(canvas)
+    native = detector is not None and hasattr(getattr(detector, "model", None), "detect_dev")
+    cm = crop_model if crop_model is not None else unet_model
+    if crop_model is not None:
+        crop_model._require()
+
+    def up(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def letterbox_dev(imgs, ch):
+        packed, offsets, shapes = pack_frames(imgs)
+        geom = np.array([letterbox_geometry(int(h), int(w), S) for h, w in shapes], np.int32)
+        o = torch.empty((len(imgs), S, S, 3) if ch == 3 else (len(imgs), S, S), dtype=torch.uint8, device=dev)
+        bufs = [up(packed), up(offsets), up(shapes), up(geom)]
+        check(lib().og_canvas_letterbox_u8_dev(unet_model._h, ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), len(imgs), ch, S, ptr(bufs[3]), 0, ptr(o)),
+              "og_canvas_letterbox_u8_dev")
+        unet_model.sync()   # the staging tensors above may be released now
+        return o
+
+    for lo in range(0, n, block):
+        fb = [np.asarray(f) for f in frames[lo:lo + block]]
+        gb = [np.asarray(g) for g in gts[lo:lo + block]]
+        B = len(fb)
+        bgr = fb[0].ndim == 3
+        img = letterbox_dev(fb, 3 if bgr else 1)                       # img_lb  (eval_bagls.py:153)
+        gt = letterbox_dev(gb, 1)                                       # gt_lb   (:154)
+        if bgr:
+            gray = torch.empty((B, S, S), dtype=torch.uint8, device=dev)
+            unet_model.bgr2gray_dev(img, B, S, S, gray)                 # gray_lb (:155)
+        else:
+            gray = img
+        boxes = [None] * B
+        if detector is not None:
+            if native:
+                bgr_in = img if bgr else gray[..., None].expand(B, S, S, 3).contiguous()
+                unet_model.sync()
+                best = detector.model.detect_dev(bgr_in, B, S, S, detector.conf)
+            for i in range(B):
+                detector.reset()                                        # :164-166: BAGLS frames are not a sequence
+                if native:
+                    boxes[i] = detector.update(best[i:i + 1, :4], best[i:i + 1, 4], S, S) if best[i, 4] >= 0 else detector.update(None, None, S, S)
+                else:
+                    f_host = img[i].cpu().numpy()
+                    boxes[i] = detector.detect(f_host if bgr else np.repeat(f_host[..., None], 3, axis=-1))
+        mask_u = torch.empty((B, S, S), dtype=torch.uint8, device=dev)
+        area_u = torch.empty(B, dtype=torch.int32, device=dev)
+        unet_model.segment_dev(gray, B, S, S, area_u, mask_dev=mask_u)
+        st_u = torch.empty((B, 3), dtype=torch.int32, device=dev)
+        check(lib().og_mask_stats_dev(unet_model._h, ptr(mask_u), ptr(gt), B, S, S, None, ptr(st_u)), "og_mask_stats_dev")
+        res = np.zeros((B, 10), np.int64)
+        if detector is not None:
+            nb = np.array([normalize_box(b, S, S) for b in boxes], np.int32)          # python-slice semantics of mask[y1:y2, x1:x2]
+            d_nb = up(nb)
+            st_yu = torch.empty((B, 3), dtype=torch.int32, device=dev)
+            check(lib().og_mask_stats_dev(unet_model._h, ptr(mask_u), ptr(gt), B, S, S, ptr(d_nb), ptr(st_yu)), "og_mask_stats_dev")
+            clamp = np.array([(-1, -1, -1, -1) if b is None else (max(0, min(S, int(b[0]))), max(0, min(S, int(b[1]))),
+                                                                  max(0, min(S, int(b[2]))), max(0, min(S, int(b[3])))) for b in boxes], np.int32)
+            d_cl = up(clamp)                                            # :181-186 clamp for the TP/FP bookkeeping
+            gt_in = torch.empty(B, dtype=torch.int32, device=dev)
+            unet_model.mask_area_dev(gt, B, S, S, d_cl, gt_in)
+            # yolo-crop+unet (:89-112, :209-222): optional crop_pad, crop, letterbox NEAREST, U-Net, project back, paste
+            cb = np.full((B, 4), -1, np.int32)
+            geo = np.zeros((B, 4), np.int32)
+            for i, b in enumerate(boxes):
+                if b is None:
+                    continue
+                x1, y1, x2, y2 = (int(v) for v in b)
+                if crop_pad:
+                    x1, y1, x2, y2 = max(0, x1 - crop_pad), max(0, y1 - crop_pad), min(S, x2 + crop_pad), min(S, y2 + crop_pad)
+                x1, y1, x2, y2 = normalize_box((x1, y1, x2, y2), S, S)
+                if x2 - x1 <= 0 or y2 - y1 <= 0:
+                    continue
+                cb[i] = (x1, y1, x2, y2)
+                geo[i] = letterbox_geometry(y2 - y1, x2 - x1, NET_SIZE)
+            d_cb, d_geo = up(cb), up(geo)
+            tiles = torch.empty((B, NET_SIZE, NET_SIZE), dtype=torch.uint8, device=dev)
+            tmask = torch.empty_like(tiles)
+            mask_c = torch.empty((B, S, S), dtype=torch.uint8, device=dev)
+            unet_model.sync()
+            check(lib().og_unet_segment_crops_u8_dev(cm._h, ptr(gray), B, S, S, ptr(d_cb), ptr(d_geo), NET_SIZE, 0.5, ptr(tiles), ptr(tmask),
+                                                     ptr(mask_c)), "og_unet_segment_crops_u8_dev")
+            cm.sync()
+            st_c = torch.empty((B, 3), dtype=torch.int32, device=dev)
+            check(lib().og_mask_stats_dev(unet_model._h, ptr(mask_c), ptr(gt), B, S, S, None, ptr(st_c)), "og_mask_stats_dev")
+            unet_model.sync()
+            yu, c, gin = st_yu.cpu().numpy(), st_c.cpu().numpy(), gt_in.cpu().numpy()
+            res[:, 3:5] = yu[:, :2]
+            res[:, 5:7] = c[:, :2]
+            res[:, 7] = [b is not None for b in boxes]
+            res[:, 8] = gin > 0
+        unet_model.sync()
+        u = st_u.cpu().numpy()
+        res[:, 0:3] = u
+        res[:, 9] = u[:, 2] > 0
+        out[lo:lo + B] = res
+    return out
+
+
+def agg_from_counts(counts: np.ndarray, has_detector: bool, has_crop: bool = True):
+    """``(agg, det_stats)`` in the reference's structure (eval_bagls.py:131-135,230) from the per-frame count rows."""
+    agg = {p: {"dice": [], "iou": [], "n_det": 0, "n_total": 0} for p in PIPELINES}
+    det_stats = {"tp": 0, "fp": 0, "fn": 0, "n_pos_gt": 0}
+    for r in counts:
+        tp_u, np_u, ng, tp_yu, np_yu, tp_c, np_c, detected, det_tp, gt_pos = (int(v) for v in r)
+        rows = [("unet-only", tp_u, np_u)]
+        if has_detector:
+            rows.append(("yolo+unet", tp_yu, np_yu))
+            if has_crop:
+                rows.append(("yolo-crop+unet", tp_c, np_c))
+            det_stats["n_pos_gt"] += gt_pos
+            if detected:
+                det_stats["tp" if det_tp else "fp"] += 1
+            elif gt_pos:
+                det_stats["fn"] += 1
+        for pipe, tp, npred in rows:
+            d, j = metrics_from_counts(tp, npred, ng)
+            agg[pipe]["dice"].append(d)
+            agg[pipe]["iou"].append(j)
+            agg[pipe]["n_total"] += 1
+            agg[pipe]["n_det"] += int(detected and pipe != "unet-only")
+    return agg, det_stats
+
+
+def evaluate_device(frames, gts, unet_model, detector=None, crop_model=None, canvas: int = NET_SIZE, crop_pad: int = 0):
+    """`scripts/eval_bagls.py:evaluate` on the device: ``(agg, det_stats)``."""
+    counts = evaluate_counts_device(frames, gts, unet_model, detector, crop_model, canvas, crop_pad)
+    return agg_from_counts(counts, detector is not None, True)

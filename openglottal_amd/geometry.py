@@ -83,6 +83,26 @@ def _pad(img: np.ndarray, top: int, bottom: int, left: int, right: int, value: i
     return np.pad(img, pads, mode="constant", constant_values=value)
 
 
+def letterbox_geometry(h: int, w: int, size: int = 256) -> tuple[int, int, int, int]:
+    """``(pad_top, pad_left, content_h, content_w)`` of a letterbox to ``size`` (utils.py:108-123, eval_bagls.py:53-63):
+    Python ``round()`` (half to even) of the scaled sides, the odd padding pixel goes to the bottom / right."""
+    scale = size / max(h, w)
+    nh, nw = int(round(h * scale)), int(round(w * scale))
+    return (size - nh) // 2, (size - nw) // 2, nh, nw
+
+
+def pack_frames(frames) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Frames of mixed sizes (all 2-D or all HxWx3, u8) back to back in one buffer for the device front end:
+    ``(packed u8 [total], offsets int64 [B], shapes int32 [B,2])``."""
+    shapes = np.array([f.shape[:2] for f in frames], np.int32).reshape(-1, 2)
+    sizes = np.array([f.size for f in frames], np.int64)
+    offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64) if len(frames) else np.zeros(0, np.int64)
+    packed = np.empty(int(sizes.sum()), np.uint8)
+    for f, o, n in zip(frames, offsets, sizes):
+        packed[o:o + n] = np.ascontiguousarray(f, dtype=np.uint8).ravel()
+    return packed, offsets, shapes
+
+
 def letterbox_with_info(img: np.ndarray, size: int = 256, value: int = 0):
     """Longest side → ``size`` (aspect preserved), symmetric constant pad (utils.py:97-134).
 

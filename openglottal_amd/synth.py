@@ -148,6 +148,37 @@ def full128_frames() -> tuple[np.ndarray, np.ndarray]:
     return np.concatenate([glot, stream], axis=0), gt
 
 
+BAGLS_SIZES_WH = ((256, 256), (512, 256), (512, 128), (352, 208))   # "256×256, 512×256, 512×128, 352×208" (scripts/eval_bagls.py:3)
+
+
+def bagls_standin(n: int = 3500, seed: int = 2020, bgr: bool = True):
+    """Stand-in for the BAGLS test split (3 500 frames of mixed sizes, each with a binary GT mask; the data set itself is
+    absent): dark rotated ellipse on a bright textured background as ``glottis_frames``, sizes drawn from
+    ``BAGLS_SIZES_WH`` (every fourth frame transposed to portrait), every 9th frame without a glottis (empty GT).
+    Returns ``(frames list of [H,W,3] (or [H,W]) u8, gts list of [H,W] u8 {0,255})``."""
+    rs = np.random.RandomState(seed)
+    frames, gts = [], []
+    for i in range(n):
+        w, h = BAGLS_SIZES_WH[rs.randint(len(BAGLS_SIZES_WH))]
+        if i % 4 == 3:
+            w, h = h, w
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        bg, dark = rs.uniform(120, 220), rs.uniform(20, 60)
+        cx, cy = w / 2 + rs.uniform(-0.15, 0.15) * w, h / 2 + rs.uniform(-0.15, 0.15) * h
+        ang = rs.uniform(-0.5, 0.5)
+        a, b_len = rs.uniform(0.01, 0.05) * min(h, w) + 1.0, rs.uniform(0.1, 0.3) * min(h, w)
+        xr = (xx - cx) * np.cos(ang) + (yy - cy) * np.sin(ang)
+        yr = -(xx - cx) * np.sin(ang) + (yy - cy) * np.cos(ang)
+        inside = ((xr / a) ** 2 + (yr / b_len) ** 2 <= 1.0) if i % 9 != 8 else np.zeros((h, w), bool)
+        img = np.where(inside, dark + rs.normal(0, 5, size=(h, w)), bg + rs.normal(0, 10, size=(h, w)))
+        g = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+        if bgr:
+            g = np.clip(g[..., None].astype(np.int32) + rs.randint(-6, 7, size=(h, w, 3)), 0, 255).astype(np.uint8)
+        frames.append(g)
+        gts.append(inside.astype(np.uint8) * 255)
+    return frames, gts
+
+
 # ── YOLOv8 detector weights (ultralytics state_dict keys) ────────────────────
 
 

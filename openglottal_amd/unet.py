@@ -201,6 +201,27 @@ class UNet:
         self._require()
         check(lib().og_mask_area_dev(self._h, ptr(mask_dev), B, H, W, ptr(boxes_dev), ptr(area_dev)), "og_mask_area_dev")
 
+    def canvas_letterbox(self, frames, size: int = 256, value: int = 0) -> np.ndarray:
+        """`letterbox` of scripts/eval_bagls.py:46-70 for a list of frames of MIXED sizes on the device: all 2-D (gray /
+        masks: NEAREST) or all ``HxWx3`` (BGR: LINEAR) → ``[B,size,size(,3)]`` u8.  Pixel-identical to
+        ``geometry.letterbox`` (tests/test_gpu_bagls.py)."""
+        from .geometry import letterbox_geometry, pack_frames
+
+        self._require()
+        frames = [np.asarray(f) for f in frames]
+        B = len(frames)
+        ch = 3 if (B and frames[0].ndim == 3) else 1
+        if any((f.ndim == 3) != (ch == 3) or (f.ndim == 3 and f.shape[2] != 3) for f in frames):
+            raise OpenGlottalHipError("canvas_letterbox: frames must be all 2-D or all HxWx3")
+        out = np.empty((B, size, size, 3) if ch == 3 else (B, size, size), np.uint8)
+        if B == 0:
+            return out
+        packed, offsets, shapes = pack_frames(frames)
+        geom = np.array([letterbox_geometry(int(h), int(w), size) for h, w in shapes], np.int32)
+        check(lib().og_canvas_letterbox_u8(self._h, ptr(packed), ptr(offsets), ptr(shapes), B, ch, int(size), ptr(geom), int(value), ptr(out)),
+              "og_canvas_letterbox_u8")
+        return out
+
     def sync(self) -> None:
         self._require()
         check(lib().og_unet_sync(self._h), "og_unet_sync")

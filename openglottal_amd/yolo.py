@@ -87,6 +87,16 @@ class YoloV8Detector:
         check(lib().og_yolo_detect_u8(self._h, ptr(f), B, H, W, float(conf), ptr(best), ptr(pred)), "og_yolo_detect_u8")
         return (best, pred) if want_pred else best
 
+    def detect_dev(self, bgr_dev, B: int, H: int, W: int, conf: float = 0.25) -> np.ndarray:
+        """``[B,H,W,3]`` u8 BGR frames RESIDENT ON THE DEVICE at network size (sides multiples of 32) → ``best [B,5]`` on the
+        host (20 bytes per frame come back)."""
+        import torch
+
+        best = torch.empty((B, 5), dtype=torch.float32, device=bgr_dev.device)
+        check(lib().og_yolo_detect_u8_dev(self._h, ptr(bgr_dev), B, H, W, float(conf), ptr(best), None), "og_yolo_detect_u8_dev")
+        check(lib().og_yolo_sync(self._h), "og_yolo_sync")
+        return best.cpu().numpy()
+
     def detect_frames(self, frames_bgr, conf: float = 0.25) -> np.ndarray:
         """Frames of ONE size ``[B,H,W,3]`` (or ``[B,H,W]`` gray) at their ORIGINAL resolution → ``best [B,5]`` in
         original-frame pixels (conf = -1: no detection): what the ultralytics predictor does per call of

@@ -117,3 +117,88 @@ def test_gated_waveform_world2_equals_single_process():
         p.join(60)
     for rank, wave, boxes in res:
         assert wave == ref_wave.tolist() and boxes == ref_boxes.tolist(), rank
+
+
+# ── C5: stateless (per-frame reset) evaluation sharded over ranks: one all-gather of integer count rows ──────────────
+
+
+def _fake_counts(lo, hi):
+    k = np.arange(lo, hi, dtype=np.int64)
+    return np.stack([k * 7 % 1000, k * 7 % 1000 + k % 13, k * 5 % 900, k % 50, k % 60, k % 70, k % 80, k % 2, k % 3 == 0, k % 9 != 8], axis=1)
+
+
+def _eval_worker(rank, world, port, n, q):
+    from openglottal_amd.dist import sharded_eval_counts
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    got = sharded_eval_counts(n, _fake_counts, rank, world)
+    q.put((rank, np.array_equal(got, _fake_counts(0, n))))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [3500, 37, 1])
+def test_sharded_eval_counts_world2_equals_single_process(n):
+    from openglottal_amd import evaluate as E
+    from openglottal_amd.dist import sharded_eval_counts
+    one = sharded_eval_counts(n, _fake_counts, 0, 1)
+    assert np.array_equal(one, _fake_counts(0, n))
+    agg, st = E.agg_from_counts(one, True, True)          # the table is a pure function of the gathered rows
+    assert agg["yolo-crop+unet"]["n_total"] == n and len(agg["unet-only"]["dice"]) == n
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_eval_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=180) for _ in ps]
+    for p in ps:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+# ── world 8 (one rank per GPU of the node) rehearsed on CPU: BASELINE config C4's N = 10 000 and a ragged N ─────────
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _w8_worker(rank, world, port, n, q):
+    import openglottal_amd as og
+    from openglottal_amd.dist import all_gather_rows, sharded_gated_area_waveform
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = (np.arange(n, dtype=np.int64) * 37 % 65537).astype(np.int32)
+    lo, hi = shard_range(n, rank, world)
+    wave = all_gather_areas(torch.from_numpy(full[lo:hi].copy()), n)          # plain: int32 areas (C4)
+    rows = all_gather_rows(torch.from_numpy(np.stack([full[lo:hi]] * 5, 1).astype(np.float32) / 4), n, 5)   # gated: 5-float boxes
+    ok = np.array_equal(wave.numpy(), full) and np.array_equal(rows.numpy()[:, 3], full.astype(np.float32) / 4)
+    # gated pipeline end to end on a short ragged video (state machine replayed on every rank)
+    m = 43
+    gw, gb = sharded_gated_area_waveform(list(_frames(m)), _fake_detect, lambda: og.TemporalDetector(lambda f, c: None), _FakeModel(), rank, world)
+    q.put((rank, bool(ok), gw.tolist(), gb.tolist()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [10000, 10003])
+def test_world8_plain_and_gated_gathers_equal_single_process(n):
+    import openglottal_amd as og
+    from openglottal_amd.dist import sharded_gated_area_waveform
+    ref_w, ref_b = sharded_gated_area_waveform(list(_frames(43)), _fake_detect, lambda: og.TemporalDetector(lambda f, c: None), _FakeModel(), 0, 1)
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_w8_worker, args=(r, 8, port, n, q)) for r in range(8)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(60)
+    assert sorted(r[0] for r in res) == list(range(8))
+    for rank, ok, gw, gb in res:
+        assert ok, rank
+        assert gw == ref_w.tolist() and gb == ref_b.tolist(), rank
