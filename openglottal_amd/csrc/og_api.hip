@@ -46,6 +46,7 @@ struct ConvLayer {  // one 3x3 conv + BN + ReLU, or one 2x2 transposed conv
     int Cin_p = 0, Cout_p = 0;  // padded (buffer) channel counts
     int NT = 1;
     float* d_w = nullptr;
+    float* d_w_h = nullptr;   // the same weights as f16 hi/lo pairs in the H layout (opt-in split precision)
     float* d_scale = nullptr;
     float* d_shift = nullptr;
 };
@@ -165,6 +166,8 @@ struct og_unet {
         bool mask = false, logits = false;
         hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     } ring;
+    int precision = 0;     // 0: exact f32 (v_mfma_f32_32x32x2_f32) -- the default and the parity reference; 1: opt-in split precision
+                           // (f16 hi/lo pairs, 3 x v_mfma_f32_32x32x16_f16 per f32 product, f32 accumulation; k_conv_mfma_h)
     int stream_host = 1;   // og_unet_segment_u8 goes through the streaming engine (0: one-shot staging of the whole batch)
 };
 
@@ -219,6 +222,35 @@ std::vector<float> pack_gemm_b(int Ncols_p, int Kp, int taps, int NT, F&& weight
     return out;
 }
 
+// Split-precision image of the same weights (og_kernels.hpp "H layout"): per (row, chunk, tap) the 128 bytes hold eight
+// 16-byte slots, logical slot s < 4 = f16 hi of k = 32c + 8s .. +7, slot 4+s = f16 lo (scaled by 2^11) of the same k;
+// physical slot = logical ^ ((r>>1)&7) as in the f32 image.  Same byte size, so it is carried in a float vector.
+template <typename F>
+std::vector<float> pack_gemm_b_h(int Ncols_p, int Kp, int taps, int NT, F&& weight_at /*(n, k, tap)->float*/) {
+    const int rows = 32 * NT;
+    const int n_tiles = Ncols_p / rows;
+    const int n_chunks = Kp / 32;
+    std::vector<float> out((size_t)Ncols_p * Kp * taps, 0.f);
+    _Float16* o16 = (_Float16*)out.data();
+    size_t o = 0;   // in halves
+    for (int nt = 0; nt < n_tiles; ++nt)
+        for (int c = 0; c < n_chunks; ++c)
+            for (int t = 0; t < taps; ++t) {
+                for (int r = 0; r < rows; ++r)
+                    for (int ps = 0; ps < 8; ++ps) {
+                        const int sl = ps ^ ((r >> 1) & 7);
+                        for (int e = 0; e < 8; ++e) {
+                            const float w = weight_at(nt * rows + r, c * 32 + (sl & 3) * 8 + e, t);
+                            const _Float16 hi = (_Float16)w;
+                            const _Float16 lo = (_Float16)((w - (float)hi) * 2048.0f);
+                            o16[o + (size_t)r * 64 + ps * 8 + e] = (sl < 4) ? hi : lo;
+                        }
+                    }
+                o += (size_t)rows * 64;
+            }
+    return out;
+}
+
 int upload(const std::vector<float>& v, float** d) {
     HIPCHK(hipMalloc((void**)d, v.size() * sizeof(float)));
     HIPCHK(hipMemcpy(*d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -246,6 +278,7 @@ int build_conv(og_unet* h, ConvLayer& L, const std::string& wkey, const std::str
     fold_bn(h, bnkey, Cout, L.Cout_p, sc, sh);
     int rc;
     if ((rc = upload(pk, &L.d_w))) return rc;
+    if ((rc = upload(pack_gemm_b_h(L.Cout_p, L.Cin_p, 9, L.NT, at), &L.d_w_h))) return rc;
     if ((rc = upload(sc, &L.d_scale))) return rc;
     if ((rc = upload(sh, &L.d_shift))) return rc;
     return OG_OK;
@@ -275,6 +308,7 @@ int build_convT(og_unet* h, ConvLayer& L, const std::string& p, int Cin, int Cou
     }
     int rc;
     if ((rc = upload(pk, &L.d_w))) return rc;
+    if ((rc = upload(pack_gemm_b_h(4 * Cop, L.Cin_p, 1, L.NT, at), &L.d_w_h))) return rc;
     if ((rc = upload(sc, &L.d_scale))) return rc;
     if ((rc = upload(sh, &L.d_shift))) return rc;
     return OG_OK;
@@ -288,9 +322,10 @@ std::vector<int> ident_map(int Cin) {
 
 void free_layer(ConvLayer& L) {
     if (L.d_w) (void)hipFree(L.d_w);
+    if (L.d_w_h) (void)hipFree(L.d_w_h);
     if (L.d_scale) (void)hipFree(L.d_scale);
     if (L.d_shift) (void)hipFree(L.d_shift);
-    L.d_w = L.d_scale = L.d_shift = nullptr;
+    L.d_w = L.d_w_h = L.d_scale = L.d_shift = nullptr;
 }
 
 void drop_graphs(og_unet* h) {
@@ -439,6 +474,31 @@ int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     return OG_OK;
 }
 
+template <int NT, int MODE, int TH, int OCC>
+int launch_conv_h(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {   // split-precision twin of launch_conv_o (no split-K)
+    constexpr int lds = conv_o_lds<NT, MODE, TH>();
+    ConvArgs a = a_in;
+    a.stamps = nullptr;
+    a.ksplit = 1;
+    a.tile_counter = nullptr;
+    const int frames = a.n_spatial / (a.tiles_x * a.tiles_y);
+    a.zdiv = n_ntiles;
+    a.frames = frames;
+    a.zgroup_shift = 0;
+    if (c.xcd_group && a.zdiv > 1) {
+        int txy = a.tiles_x * a.tiles_y, g = 8;
+        while (g > 1 && txy % 2 == 0) { txy /= 2; g /= 2; }
+        while (g > frames) g /= 2;
+        while ((1 << a.zgroup_shift) < g) ++a.zgroup_shift;
+    }
+    const int G = 1 << a.zgroup_shift, groups = (frames + G - 1) / G;
+    a.zrcp = 1.0f / (float)(a.zdiv * G);
+    if ((long long)groups * G * a.zdiv > 65535) return fail(OG_EINVAL, "micro-batch too large for one launch (grid.z): lower the chunk size");
+    hipLaunchKernelGGL((k_conv_mfma_h<NT, MODE, TH, OCC>), dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), lds, c.stream, a);
+    HIPCHK(hipGetLastError());
+    return OG_OK;
+}
+
 template <int NT, int MODE, int TH, int TPS>
 int launch_conv_p(const LaunchCtx& c, const ConvArgs& a, int n_ntiles) {
     constexpr int lds = conv_p_lds<NT, MODE, TH, TPS>();
@@ -494,6 +554,12 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 8>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<1, 0, 8, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               conv_o_lds<1, 0, 8>() + (12 * 20 + 352) * 4));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<2, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 16>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<2, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 8>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<1, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 8>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<2, 1, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 1, 8>()));
     if ((rc = set_conv_p_attr<2, 0, 16, 1>())) return rc;
     if ((rc = set_conv_p_attr<2, 0, 16, 3>())) return rc;
     if ((rc = set_conv_p_attr<1, 0, 16, 3>())) return rc;
@@ -570,6 +636,40 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     a.ksplit = 1;
     a.partial = h->d_partial;
     a.tile_counter = (h->splitk_fused && h->d_tile_counter) ? h->d_tile_counter : nullptr;
+    if (h->precision == 1) {   // opt-in split precision: always the occupancy-shaped kernel, no split-K
+        if (a.head_w != nullptr) big = false;
+        const int th_h = big ? 16 : 8;
+        a.tiles_y = (in.H + th_h - 1) / th_h;
+        a.n_spatial = B * a.tiles_x * a.tiles_y;
+        a.wpk = L.d_w_h;
+        a.stamps = nullptr;
+        const double px_h = (double)B * in.H * in.W;
+        int rc_h;
+        if (L.mode == 0) {
+            if (out.H != in.H || out.W != in.W) return fail(OG_EINVAL, "conv shape mismatch");
+            const int n_ntiles = L.Cout_p / (32 * L.NT);
+            const double fl = 2.0 * px_h * 9.0 * L.Cin * L.Cout;
+            if (big && L.NT == 2) {
+                prof_begin(h, L.name, "k_conv_mfma_h<2,0,16>", fl);
+                rc_h = launch_conv_h<2, 0, 16, 2>(ctx, a, n_ntiles);
+            } else {
+                if (big) {   // 16-row tiles exist for the 64-column kernel only
+                    a.tiles_y = (in.H + 7) / 8;
+                    a.n_spatial = B * a.tiles_x * a.tiles_y;
+                }
+                prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma_h<2,0,8>" : "k_conv_mfma_h<1,0,8>", fl);
+                rc_h = (L.NT == 2) ? launch_conv_h<2, 0, 8, 3>(ctx, a, n_ntiles) : launch_conv_h<1, 0, 8, 3>(ctx, a, n_ntiles);
+            }
+        } else {
+            if (out.H != 2 * in.H || out.W != 2 * in.W) return fail(OG_EINVAL, "convT shape mismatch");
+            a.tiles_y = (in.H + 7) / 8;
+            a.n_spatial = B * a.tiles_x * a.tiles_y;
+            prof_begin(h, L.name, "k_conv_mfma_h<2,1,8>", 2.0 * px_h * 4.0 * L.Cin * L.Cout);
+            rc_h = launch_conv_h<2, 1, 8, 3>(ctx, a, 4 * L.Cout_p / 64);
+        }
+        prof_end(h);
+        return rc_h;
+    }
     int impl = h->conv_impl;
     if (impl == 1 || impl == 2) {
         const int nt = (L.mode == 0) ? L.Cout_p / (32 * L.NT) : 4 * L.Cout_p / 64;
@@ -693,8 +793,14 @@ int enqueue_first(og_unet* h, int kind, const void* in, int B, int H, int W) {
     const Act& o = h->A[0];
     prof_begin(h, "downs.0.net.0.weight", kind == KIND_U8 ? "k_conv_first<u8>" : "k_conv_first<f32>",
                2.0 * B * H * W * 9.0 * h->features[0]);
-    if (kind == KIND_U8)
+    if (kind == KIND_U8 && h->precision == 1)
+        hipLaunchKernelGGL((k_conv_first<uint8_t, true>), dim3(B * tiles), dim3(256), 0, h->stream, (const uint8_t*)in, o.p,
+                           h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride());
+    else if (kind == KIND_U8)
         hipLaunchKernelGGL(k_conv_first<uint8_t>, dim3(B * tiles), dim3(256), 0, h->stream, (const uint8_t*)in, o.p,
+                           h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride());
+    else if (h->precision == 1)
+        hipLaunchKernelGGL((k_conv_first<float, true>), dim3(B * tiles), dim3(256), 0, h->stream, (const float*)in, o.p,
                            h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride());
     else
         hipLaunchKernelGGL(k_conv_first<float>, dim3(B * tiles), dim3(256), 0, h->stream, (const float*)in, o.p,
@@ -725,7 +831,7 @@ int enqueue_first_fused(og_unet* h, const uint8_t* gray, int B, int H, int W) {
     a.tiles_x = (W + 15) / 16;
     a.tiles_y = (H + 7) / 8;
     a.n_spatial = B * a.tiles_x * a.tiles_y;
-    a.wpk = L.d_w;
+    a.wpk = (h->precision == 1) ? L.d_w_h : L.d_w;
     a.scale = L.d_scale;
     a.shift = L.d_shift;
     a.aff_mod = L.Cout_p;
@@ -744,19 +850,24 @@ int enqueue_first_fused(og_unet* h, const uint8_t* gray, int B, int H, int W) {
     a.first_scale = h->d_first_scale;
     a.first_shift = h->d_first_shift;
     constexpr int lds = conv_o_lds<1, 0, 8>() + (12 * 20 + 352) * 4;
-    prof_begin(h, "downs.0 (first + second conv fused)", "k_conv_mfma_o<1,0,8,FIRST>",
+    prof_begin(h, "downs.0 (first + second conv fused)", h->precision == 1 ? "k_conv_mfma_h<1,0,8,FIRST>" : "k_conv_mfma_o<1,0,8,FIRST>",
                2.0 * B * H * W * 9.0 * (1.0 * h->features[0] + (double)h->features[0] * h->features[0]));
     a.zdiv = 1;
     a.zrcp = 1.0f;
     a.zgroup_shift = 0;
     a.frames = B;
-    hipLaunchKernelGGL((k_conv_mfma_o<1, 0, 8, 3, true>), dim3(a.tiles_x, a.tiles_y, B), dim3(256), lds, h->stream, a);
+    if (h->precision == 1) a.prio_mode = h->prio_mode;
+    if (h->precision == 1)
+        hipLaunchKernelGGL((k_conv_mfma_h<1, 0, 8, 3, true>), dim3(a.tiles_x, a.tiles_y, B), dim3(256), lds, h->stream, a);
+    else
+        hipLaunchKernelGGL((k_conv_mfma_o<1, 0, 8, 3, true>), dim3(a.tiles_x, a.tiles_y, B), dim3(256), lds, h->stream, a);
     prof_end(h);
     HIPCHK(hipGetLastError());
     return OG_OK;
 }
 
 bool can_fuse_head(const og_unet* h) {
+    if (h->precision == 1 && h->keep_taps) return false;   // the fused head keeps the f32 scratch: no H-layout activation to tap
     return h->fuse_head && h->conv_impl != 0 && cp32(h->features[0]) == 32;
 }
 
@@ -818,8 +929,12 @@ int enqueue_head(og_unet* h, int B, int H, int W, float thr, const int32_t* boxe
     const int HW = H * W;
     const int bpf = (HW + 1023) / 1024;
     prof_begin(h, "head", "k_head", 2.0 * B * HW * h->features[0]);
-    hipLaunchKernelGGL(k_head, dim3(B * bpf), dim3(256), 0, h->stream, u.p, u.frame_stride(), u.C, h->d_head_w,
-                       h->head_bias, cp32(h->features[0]), HW, W, thr, boxes, logits, mask, area, bpf);
+    if (h->precision == 1)
+        hipLaunchKernelGGL(k_head<true>, dim3(B * bpf), dim3(256), 0, h->stream, u.p, u.frame_stride(), u.C, h->d_head_w,
+                           h->head_bias, cp32(h->features[0]), HW, W, thr, boxes, logits, mask, area, bpf);
+    else
+        hipLaunchKernelGGL(k_head<false>, dim3(B * bpf), dim3(256), 0, h->stream, u.p, u.frame_stride(), u.C, h->d_head_w,
+                           h->head_bias, cp32(h->features[0]), HW, W, thr, boxes, logits, mask, area, bpf);
     prof_end(h);
     HIPCHK(hipGetLastError());
     return OG_OK;
@@ -846,7 +961,7 @@ int run_chunk(og_unet* h, int kind, const void* in, int B, int H, int W, float t
         key.B = B;
         key.H = H;
         key.W = W;
-        key.flags = (fuse ? 1 : 0) | (ff ? 2 : 0);
+        key.flags = (fuse ? 1 : 0) | (ff ? 2 : 0) | (h->precision ? 4 : 0);
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
             hipGraph_t g = nullptr;
@@ -1293,6 +1408,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "dual" && (value == 0 || value == 1)) slot = &h->dual;
     else if (n == "lanes" && value >= 0 && value <= kMaxLanes) slot = &h->n_lanes;
     else if (n == "stream" && (value == 0 || value == 1)) slot = &h->stream_host;
+    else if (n == "precision" && (value == 0 || value == 1)) slot = &h->precision;
     if (!slot) return fail(OG_EINVAL, "unknown option or bad value: " + n);
     if (*slot != value) {
         if (h->stream) HIPCHK(hipStreamSynchronize(h->stream));
@@ -1705,6 +1821,19 @@ int og_unet_get_activation(og_unet* h, const char* name, int B, float* out, size
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(tmp.data(), a->p, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
     const size_t HW = (size_t)a->H * a->W;
+    if (h->precision == 1) {   // H layout: channel c of a pixel = hi + lo * 2^-11, hi / lo halves of its 32-channel chunk
+        const _Float16* t16 = (const _Float16*)tmp.data();
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < C; ++c) {
+                const int cc = off + c, chunk = cc / 32, w = cc % 32;
+                const size_t hoff = (size_t)chunk * 64 + (size_t)(w / 8) * 8 + (w % 8);   // in halves, within the pixel
+                for (size_t p = 0; p < HW; ++p) {
+                    const _Float16* px = t16 + ((size_t)b * HW + p) * a->C * 2;
+                    out[((size_t)b * C + c) * HW + p] = (float)px[hoff] + (float)px[hoff + 32] * (1.0f / 2048.0f);
+                }
+            }
+        return OG_OK;
+    }
     for (int b = 0; b < B; ++b)
         for (int c = 0; c < C; ++c)
             for (size_t p = 0; p < HW; ++p) out[((size_t)b * C + c) * HW + p] = tmp[((size_t)b * HW + p) * a->C + off + c];

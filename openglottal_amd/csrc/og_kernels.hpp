@@ -98,6 +98,29 @@ __device__ __forceinline__ unsigned og_lds_addr(const void* p) {
     return (unsigned)(size_t)((OG_LDS_AS const unsigned char*)p);
 }
 
+// ---- split precision (opt-in "precision" 1, never the default): an f32 value v travels as TWO f16 numbers,
+//   hi = f16(v),  lo = f16((v - hi) * 2^11)      =>   v = hi + lo * 2^-11  to ~2^-22 relative,
+// and a product a*b is taken as  a_hi*b_hi + 2^-11 * (a_hi*b_lo + a_lo*b_hi)  on v_mfma_f32_32x32x16_f16 with f32
+// accumulation (two accumulators, combined once in the epilogue): 3 f16 MFMAs of 32 cycles for 16 k, against 8 f32
+// MFMAs of 64 cycles.  The 2^11 scale keeps `lo` out of the f16 subnormals (the MFMA does keep subnormal inputs --
+// tools/ubench/mfma_f16_split -- but they carry fewer bits).  Emulated on the CPU against the reference fixture: max
+// |dlogit| 1.4e-5, the same as plain f32 re-association noise (1.3e-5); tolerance 5e-5.  |v| must stay below 65504.
+// "H layout" of a 32-channel chunk of one pixel (128 bytes, as the f32 layout): eight 16-byte slots, slot s < 4 = hi of
+// channels 8s..8s+7, slot 4+s = lo of the same channels -- so the LDS images, the DMA staging, the swizzles and every
+// store address of the f32 kernels carry over unchanged; only fragment contents and the MFMA differ.
+typedef _Float16 og_h8 __attribute__((ext_vector_type(8)));
+constexpr float OG_LO_SCALE = 2048.0f, OG_LO_INV = 1.0f / 2048.0f;
+__device__ __forceinline__ void og_split(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * OG_LO_SCALE);
+}
+__device__ __forceinline__ f32x4 og_pack8(const _Float16* h) {
+    og_h8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = h[e];
+    return __builtin_bit_cast(f32x4, v);
+}
+
 struct ConvArgs {
     const float* in;        // NHWC, frame-major
     long long in_frame_stride;   // floats per frame
@@ -484,7 +507,7 @@ __device__ __forceinline__ void og_buffer_store16(f32x4 v, __amdgpu_buffer_rsrc_
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(og_u32x4, v), rs, voff, soff, 0);
 #endif
 }
-template <int NT, int MODE, int TH, int ACT, bool RES>
+template <int NT, int MODE, int TH, int ACT, bool RES, bool HALF = false>
 __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16* acc, int n_tile, int b, int ty0, int tx0, int wm, int wn,
                                                 int li, int lh, float sc, float sh, unsigned char* scratch) {
     constexpr int WROWS = 32 * NT;
@@ -558,7 +581,15 @@ __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16*
                     if (y < a.H && x < a.W)
                         v += a.res[(long long)b * a.res_frame_stride + ((long long)y * OW + x) * a.res_pix_stride + a.res_ch_off + cbase + li];
                 }
-                fw[(8 * g + rr) * 32] = v;
+                if (HALF && !fuse_head) {   // H layout: row i = 8g + 4lh + rr of the tile image, hi at byte 2*li, lo at 64 + 2*li
+                    _Float16 hi, lo;
+                    og_split(v, hi, lo);
+                    _Float16* const hw = (_Float16*)scratch + (256 * lh + li) + (8 * g + rr) * 64;
+                    hw[0] = hi;
+                    hw[32] = lo;
+                } else {
+                    fw[(8 * g + rr) * 32] = v;
+                }
                 vmaxs[g] = (rr == 0) ? v : fmaxf(vmaxs[g], v);
             }
         }
@@ -609,7 +640,17 @@ __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16*
             if (pool) {
                 // pooled tile: 8 windows x 32 channels = exactly one 16-B store per lane
 #pragma unroll
-                for (int g = 0; g < 4; ++g) fw[1024 - 96 * lh + g * 64] = vmaxs[g];  // fs[1024 + (2g + lh) * 32 + li]
+                for (int g = 0; g < 4; ++g) {
+                    if (HALF) {   // pooled tile image at scratch + 4096: row 2g + lh, hi at byte 2*li, lo at 64 + 2*li
+                        _Float16 hi, lo;
+                        og_split(vmaxs[g], hi, lo);
+                        _Float16* const hw = (_Float16*)scratch + 2048 + (2 * g + lh) * 64 + li;
+                        hw[0] = hi;
+                        hw[32] = lo;
+                    } else {
+                        fw[1024 - 96 * lh + g * 64] = vmaxs[g];  // fs[1024 + (2g + lh) * 32 + li]
+                    }
+                }
                 const f32x4 p4 = *(const f32x4*)(fr + 1024);
                 const int so = (((y0 >> 1) * (a.W >> 1) + (tx0 >> 1)) * a.pool_pix_stride + a.pool_ch_off + cbase) * 4;
                 og_buffer_store16(p4, pool_rs, vpool, (unsigned)so);
@@ -972,6 +1013,302 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     }
 }
 
+// Split-precision twin of k_conv_mfma_o (MODE 0 / 1): same tiles, staging, LDS images and addressing; the operands are
+// f16 hi/lo pairs in the H layout and each (chunk, tap) costs 6 x v_mfma_f32_32x32x16_f16 per 32-row sub-tile instead
+// of 16 x v_mfma_f32_32x32x2_f32.  Opt-in ("precision" 1); the f32 kernel stays the default and the parity reference.
+template <int NT, int MODE, int TH, int OCC, bool FIRST = false>
+__global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
+    static_assert(MODE == 0 || MODE == 1, "split precision: 3x3 conv and transposed conv only");
+    constexpr int TW = 16;
+    constexpr int PAD = (MODE == 0 || MODE == 3) ? 1 : 0;                 // rows/columns of halo above / left of the tile
+    constexpr int HW_ = (MODE == 3) ? TW + 2 : TW + 2 * PAD;             // MODE 3 needs 17 columns; an even pitch keeps
+    constexpr int HH_ = (MODE == 3) ? TH + 1 : TH + 2 * PAD;             // the slot swizzle conflict-free
+    constexpr int HALO_PIX = HW_ * HH_;
+    constexpr int HALO_BYTES = HALO_PIX * 128;
+    constexpr int HALO_PIECES = HALO_PIX * 8;
+    constexpr int HALO_IT = (HALO_PIECES + 255) / 256;
+    constexpr int TAPS = (MODE == 0) ? 9 : (MODE == 3) ? 4 : 1;
+    constexpr int WROWS = 32 * NT;
+    constexpr int WBYTES = WROWS * 128;
+    // weight ring: 3 stages for the 3x3 conv, so that a tap's stage (t % 3, nine taps per chunk) is a compile-time
+    // constant and the B-fragment reads need no address arithmetic; 2 stages (runtime parity) elsewhere
+    constexpr int NSTG = (MODE == 0) ? 3 : 2;
+    constexpr int WM = 4 / NT;
+    constexpr int MS = (TH / 2) / WM;  // 32-row M sub-tiles (2 pixel rows x 16) per wave
+    static_assert(MS >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const halo0 = smem;
+    unsigned char* const wbuf0 = smem + HALO_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % NT;
+    const int wm = wave / NT;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+
+    // A young wave's VALU/VMEM instructions only get issue slots between the MFMAs of the older waves on its SIMD
+    // (measured: 14 k cycles from entry to the first DMA, 12 k for the epilogue, vs 17 k in the main loop of a
+    // 32-channel layer - tools/ubench/occ_timeline).  Raise the priority outside the main loop so that the address
+    // set-up, the DMA issue and the epilogue are served first; the main loops only need a slot every 64 cycles.
+    if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(3);
+    // diagnostic timeline (tools/ubench/occ_timeline.hip only; nullptr on every product path)
+    unsigned long long* const st = a.stamps ? a.stamps + 8ull * (((unsigned long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) : nullptr;
+    if (st != nullptr && tid == 0) {
+        st[0] = __builtin_amdgcn_s_memtime();
+        st[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID: wave slot, SIMD, CU, SE
+        st[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_REG_XCC_ID
+    }
+
+    // ---- tile decode (scalar).  3-D grid (tile column, tile row, frame x column tile x K part): no integer division
+    //      on the way to the first DMA (each one is ~20 vector-ALU instructions, paid at the contended issue rate).
+    //      split-K (latency mode, MODE 0/1): K part = a range of (chunk, tap) steps ----
+    constexpr int ks_n = 1;   // no split-K in this mode
+    // grid.z = frame group q x (column tile, K part) x frame-in-group: the column tiles of one spatial tile then sit
+    // G * tiles_x * tiles_y (a multiple of 8) blocks apart = on the same XCD, dispatched together, and share the input
+    // tile in that XCD's L2 (G = 2^zgroup_shift frames per group; 1 when tiles_x * tiles_y is already a multiple of 8)
+    const int bz = (int)blockIdx.z;
+    const int gz = a.zdiv << a.zgroup_shift;
+    const int q = (gz == 1) ? bz : (int)(((float)bz + 0.5f) * a.zrcp);   // zrcp = 1 / gz; exact for bz < 2^16
+    const int rz = bz - q * gz;
+    const int zr = rz >> a.zgroup_shift;                                   // column tile x K parts + K part
+    const int b = (q << a.zgroup_shift) + (rz & ((1 << a.zgroup_shift) - 1));
+    if (b >= a.frames) return;   // tail of the last frame group (whole workgroup, before any barrier)
+    const int n_tile = (ks_n == 1) ? zr : zr / ks_n;
+    const int kpart = (ks_n == 1) ? 0 : zr - n_tile * ks_n;
+    constexpr int TAPS_ = (MODE == 0) ? 9 : 1;
+    const int s_lo = (ks_n == 1) ? 0 : (kpart * a.n_chunks * TAPS_) / ks_n;
+    const int s_hi = (ks_n == 1) ? a.n_chunks * TAPS_ : ((kpart + 1) * a.n_chunks * TAPS_) / ks_n;
+    const int c_lo = (ks_n == 1) ? 0 : s_lo / TAPS_;
+    const int c_hi = (ks_n == 1) ? a.n_chunks : (s_hi + TAPS_ - 1) / TAPS_;
+    const int ty0 = (int)blockIdx.y * TH;
+    const int tx0 = (int)blockIdx.x * TW;
+    // linear ids (split-K partial buffer, diagnostic stamps): as k_splitk_epilogue decodes them
+    const int tile_id = n_tile * a.n_spatial + (b * a.tiles_y + (int)blockIdx.y) * a.tiles_x + (int)blockIdx.x;
+    const int item_id = tile_id * ks_n + kpart;
+
+    // this frame's input as a raw buffer: offsets past num_records read as zeros (= the conv's zero padding)
+    const og_i32x4 in_rsrc = og_make_rsrc(a.in + (long long)b * a.in_frame_stride + a.in_ch_off,
+                                          (unsigned)(a.in_frame_stride - a.in_ch_off) * 4u);
+
+    // ---- per-thread halo source offsets (bytes, fixed across channel chunks); pixel index walks incrementally ----
+    unsigned hoff[HALO_IT];
+    {
+        int hy = ((tid >> 3) >= HW_) ? 1 : 0;
+        int hx = (tid >> 3) - hy * HW_;
+        const int in_w = (MODE == 3) ? 2 * a.W : a.W;
+        const int row_b = in_w * a.in_pix_stride * ((MODE == 3) ? 8 : 4);   // bytes per halo row step
+        const int col_b = a.in_pix_stride * ((MODE == 3) ? 8 : 4);          // bytes per halo column step
+#pragma unroll
+        for (int it = 0; it < HALO_IT; ++it) {
+            const int logical = (tid & 7) ^ og_halo_swz(hy, hx);
+            const int gy = ty0 + hy - PAD, gx = tx0 + hx - PAD;
+            // MODE 3: (gy, gx) is a 2x2 input block = the output pixel grid; the block's (0,0) pixel is the base
+            const bool inb = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            hoff[it] = inb ? (unsigned)(gy * row_b + gx * col_b + logical * 16) : OG_OOB;
+            hx += 32 % HW_;
+            hy += 32 / HW_;
+            if (hx >= HW_) { hx -= HW_; hy += 1; }
+        }
+    }
+    const bool last_valid = ((HALO_IT - 1) * 256 + tid) < HALO_PIECES;
+
+    const unsigned lds0 = og_lds_addr(smem);
+    // MODE 3 (3x3 stride-2 conv as a 2x2 stride-1 conv over the space-to-depth view, never materialised):
+    // virtual chunk c = (input-pixel parity par = c / cpc, 32-channel chunk c % cpc)
+    const int cpc = (MODE == 3) ? a.n_chunks >> 2 : 1;
+    auto stage_halo = [&](int buf, int c) {
+        const unsigned base = lds0 + wave * 1024;
+        (void)buf;
+        unsigned soff = (unsigned)c * 128u;  // wave-uniform byte offset of the chunk
+        if (MODE == 3) {
+            const int par = c / cpc;
+            soff = (unsigned)((((par >> 1) * 2 * a.W + (par & 1)) * a.in_pix_stride + (c - par * cpc) * 32) * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < HALO_IT; ++it) {
+            if (it < HALO_IT - 1 || last_valid) glds16b(hoff[it], in_rsrc, soff, base + it * 4096);
+        }
+    };
+    const int total_steps = (MODE == 3) ? cpc * 9 : a.n_chunks * TAPS;  // MODE 3: only the 9 non-zero (tap, parity) pairs
+    const og_i32x4 w_rsrc = og_make_rsrc(a.wpk + (long long)n_tile * total_steps * (WROWS * 32), (unsigned)total_steps * WBYTES);
+    const unsigned woff = (unsigned)tid * 16u;
+    auto stage_w = [&](int stage, int step) {
+        const unsigned base = lds0 + HALO_BYTES + stage * WBYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) glds16b(woff, w_rsrc, (unsigned)step * WBYTES + i * 4096, base + i * 4096);
+    };
+
+    // first halo and weights are on their way before the rest of the set-up (which then hides their latency)
+    if (!FIRST) {
+        if (st != nullptr && tid == 0) st[6] = __builtin_amdgcn_s_memtime();
+        stage_halo(0, c_lo);
+        stage_w((NSTG == 3) ? s_lo % 3 : (s_lo & 1), s_lo);
+    }
+
+    // ---- fragment addressing ----
+    // A rows: i -> 2x2-window-major pixel order, so that the 4 accumulator registers
+    // (reg&3) of one lane are exactly one pooling window (see epilogue).
+    const int px0 = 2 * (li >> 2) + (li & 1);
+    const int pyl = (li >> 1) & 1;
+    const int brow = wn * 32 + li;
+    const int boff = brow * 128 + ((lh ^ ((brow >> 1) & 7)) << 4);
+    // Everything lane-dependent of an A-fragment address sits in NDX x 4 registers:
+    //   abase[dx][pat] = ((pyl*HW_ + px0+dx) * 128 + ((lh ^ swz(pyl, px0+dx)) << 4) + wave row offset) ^ (pat << 5)
+    // and a tap's dy, the k-group j and the M sub-tile m only select pat = j ^ ((dy & 1) << 1) (row parity flips slot
+    // bit 2) and add the compile-time constant (dy + 2m) * HW_ * 128, which the ds_read carries as its immediate.
+    constexpr int NDX = (MODE == 0) ? 3 : (MODE == 3) ? 2 : 1;
+    unsigned abase[NDX][4];
+#pragma unroll
+    for (int dx = 0; dx < NDX; ++dx) {
+        const int px = px0 + dx;
+        const unsigned o = (unsigned)((pyl * HW_ + px) * 128 + ((lh ^ og_halo_swz(pyl, px)) << 4) + wm * (MS * 2 * HW_ * 128));
+#pragma unroll
+        for (int pat = 0; pat < 4; ++pat) {
+            abase[dx][pat] = lds0 + (o ^ (unsigned)(pat << 5));   // absolute LDS address
+            asm volatile("" : "+v"(abase[dx][pat]));              // opaque: or hipcc re-adds the (link-time 0) smem base per read
+        }
+    }
+    unsigned bbase[4];   // B fragments: stage 0 of the weight ring, k-group j
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        bbase[jj] = lds0 + HALO_BYTES + (unsigned)(boff ^ (jj << 5));
+        asm volatile("" : "+v"(bbase[jj]));
+    }
+
+    // this lane's output channel: folded BN scale / shift, loaded now so that the epilogue does not wait for them
+    const int ecol = n_tile * WROWS + wn * 32 + li;
+    const int eco = (MODE == 1) ? ecol % a.aff_mod : ecol;
+    const float esc = a.scale[eco], esh = a.shift[eco];
+
+    f32x16 acc[MS], cor[MS];   // hi*hi | hi*lo + lo*hi (scaled by 2^11)
+#pragma unroll
+    for (int m = 0; m < MS; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[m][r] = 0.f;
+            cor[m][r] = 0.f;
+        }
+
+    if (FIRST) {
+        // halo tile of the first layer's OUTPUT, computed here: 12x20 u8 patch -> /255 -> 3x3 conv -> BN -> ReLU,
+        // written in the same swizzled [pixel][8 x 16 B] image the LDS-DMA would have produced
+        float* patch = (float*)(smem + HALO_BYTES + NSTG * WBYTES);  // [HH_+2][HW_+2]
+        float* fw = patch + (HH_ + 2) * (HW_ + 2);                // w9[9][32] | scale[32] | shift[32]
+        const uint8_t* fin = a.first_u8 + (long long)b * a.H * a.W;
+        for (int i = tid; i < (HH_ + 2) * (HW_ + 2); i += 256) {
+            const int hy = i / (HW_ + 2), hx = i - hy * (HW_ + 2);
+            const int gy = ty0 + hy - 2, gx = tx0 + hx - 2;
+            patch[i] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (float)fin[(long long)gy * a.W + gx] / 255.0f : 0.f;
+        }
+        for (int i = tid; i < 352; i += 256) fw[i] = (i < 288) ? a.first_w9[i] : (i < 320 ? a.first_scale[i - 288] : a.first_shift[i - 320]);
+        stage_w(0, 0);
+        __syncthreads();
+        // one item = (halo pixel, 8-channel group L): the fma chain of k_conv_first for 8 channels, then hi -> slot L, lo -> slot 4+L
+        for (int q = tid; q < HALO_PIX * 4; q += 256) {
+            const int p = q >> 2, L = q & 3;
+            const int hy = p / HW_, hx = p - hy * HW_;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            _Float16 hi[8], lo[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { hi[e] = (_Float16)0.f; lo[e] = (_Float16)0.f; }   // outside the image: the second conv's zero padding
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                float sacc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sacc[e] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float xv = patch[(hy + t / 3) * (HW_ + 2) + hx + t % 3];
+                    const f32x4 w0 = *(const f32x4*)(fw + t * 32 + 8 * L), w1 = *(const f32x4*)(fw + t * 32 + 8 * L + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sacc[e] = fmaf(xv, w0[e], sacc[e]);
+                        sacc[4 + e] = fmaf(xv, w1[e], sacc[4 + e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = fmaxf(fmaf(sacc[e], fw[288 + 8 * L + e], fw[320 + 8 * L + e]), 0.f);
+                    og_split(v, hi[e], lo[e]);
+                }
+            }
+            const int swz = og_halo_swz(hy, hx);
+            *(f32x4*)(halo0 + p * 128 + ((L ^ swz) << 4)) = og_pack8(hi);
+            *(f32x4*)(halo0 + p * 128 + (((L + 4) ^ swz) << 4)) = og_pack8(lo);
+        }
+    }
+    og_wait_dma();
+    if (st != nullptr && tid == 0) st[7] = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    if (st != nullptr && tid == 0) st[1] = __builtin_amdgcn_s_memtime();
+    if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(0);
+
+    int step = s_lo;                             // absolute (chunk, tap) index: also the weight block's index
+    const int step_end = (MODE == 3) ? total_steps : s_hi;
+    for (int c = c_lo; c < c_hi; ++c) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            if ((MODE == 0 || MODE == 1) && ks_n > 1 && (c * TAPS + t < s_lo || c * TAPS + t >= s_hi)) continue;  // another K part's step
+            if (MODE == 3) {  // tap (ty,tx) of the 2x2 kernel meets parity (py,px): zero unless (ty==1 || py==1) and (tx==1 || px==1)
+                const int par = c / cpc;
+                if (((t >> 1) == 0 && (par & 2) == 0) || ((t & 1) == 0 && (par & 1) == 0)) continue;
+            }
+            const int stg = (NSTG == 3) ? t % 3 : (step & 1), stg_next = (NSTG == 3) ? (t + 1) % 3 : ((step + 1) & 1);
+            if (step + 1 < step_end) stage_w(stg_next, step + 1);
+
+            const unsigned wb = (unsigned)stg * WBYTES;
+            const int dy = (MODE == 0) ? t / 3 : (MODE == 3) ? (t >> 1) : 0;
+            const int dx = (MODE == 0) ? t % 3 : (MODE == 3) ? (t & 1) : 0;
+            // k-group j -> 16-byte slot 2j + lh of the 128-byte row: j = 0,1 the hi halves of k-steps 0,1 (channels 16t + 8lh ..),
+            // j = 2,3 their lo halves -- the same four reads per fragment as the f32 kernel, other contents
+            f32x4 bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = og_lds_read16(bbase[j] + wb);
+#pragma unroll
+            for (int m = 0; m < MS; ++m) {
+                f32x4 av[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[j] = og_lds_read16(abase[dx][j ^ ((dy & 1) << 1)] + (unsigned)((dy + 2 * m) * (HW_ * 128)));
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(og_h8, av[t2]), __builtin_bit_cast(og_h8, bv[t2]), acc[m], 0, 0, 0);
+                    cor[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(og_h8, av[t2]), __builtin_bit_cast(og_h8, bv[2 + t2]), cor[m], 0, 0, 0);
+                    cor[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(og_h8, av[2 + t2]), __builtin_bit_cast(og_h8, bv[t2]), cor[m], 0, 0, 0);
+                }
+            }
+            og_wait_dma();
+            __syncthreads();
+            ++step;
+        }
+        if (c + 1 < c_hi) {  // every read of the halo buffer completed before the barrier above
+            stage_halo(0, c + 1);
+            og_wait_dma();
+            __syncthreads();
+        }
+    }
+
+    if (st != nullptr && tid == 0) st[2] = __builtin_amdgcn_s_memtime();
+    if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(3);
+    // ---- epilogue (all staging buffers are dead behind the last barrier: LDS is scratch now) ----
+#pragma unroll
+    for (int m = 0; m < MS; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = fmaf(cor[m][r], OG_LO_INV, acc[m][r]);
+    {
+        unsigned char* const scr = smem + wave * 5120;
+        // activations leave in the H layout; the launch with the fused head stores no activation and keeps the f32 scratch
+        if (a.act == 1) conv_epilogue_b<NT, MODE, TH, 1, false, true>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+        else conv_epilogue_b<NT, MODE, TH, 0, false, true>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+    }
+    if (st != nullptr && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st[3] = __builtin_amdgcn_s_memtime();
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------
 // Generation 2 of the implicit-GEMM conv: PERSISTENT workgroups walking a flat sequence of
 // (item = (n_tile, frame, spatial tile), 32-channel chunk, tap-group) steps.
@@ -1314,7 +1651,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(ConvArgs a) {
 // (fuses `inp.astype(float32) / 255.0`, utils.py:235) or from an f32 NCHW input
 // (UNet.__call__ parity path).  Bandwidth-bound (AI 4.4 F/B): plain
 // VALU, 8 lanes per pixel x 4 channels each -> 1 KiB fully coalesced stores.
-template <typename IN_T>
+template <typename IN_T, bool HOUT = false>
 __global__ __launch_bounds__(256) void k_conv_first(const IN_T* __restrict__ in, float* __restrict__ out,
                                                     const float* __restrict__ w9,  // [9][Cp]
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
@@ -1342,6 +1679,28 @@ __global__ __launch_bounds__(256) void k_conv_first(const IN_T* __restrict__ in,
     const int cq = threadIdx.x & 7;
     float* fout = out + (long long)b * out_frame_stride;
     for (int cg = 0; cg < Cp; cg += 32) {
+        if (HOUT) {
+            // split-precision output (H layout): lane cq writes 16-byte slot cq of the pixel's 128-byte chunk = hi (cq < 4)
+            // or lo (cq >= 4) of channels 8(cq&3)..+7; the same fma chain per channel as below
+            const int c8 = cg + (cq & 3) * 8;
+            for (int pp = threadIdx.x >> 3; pp < 256; pp += 32) {
+                const int py = pp >> 4, px = pp & 15;
+                const int y = ty0 + py, x = tx0 + px;
+                _Float16 hl[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float sv = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) sv = fmaf(tile[py + t / 3][px + t % 3], w9[t * Cp + c8 + e], sv);
+                    const float v = fmaxf(fmaf(sv, scale[c8 + e], shift[c8 + e]), 0.f);
+                    _Float16 hi, lo;
+                    og_split(v, hi, lo);
+                    hl[e] = (cq < 4) ? hi : lo;
+                }
+                if (y < H && x < W) *(f32x4*)(fout + ((long long)y * W + x) * out_pix_stride + cg + cq * 4) = og_pack8(hl);
+            }
+            continue;
+        }
         const int c0 = cg + cq * 4;
         f32x4 wv[9];
 #pragma unroll
@@ -1373,6 +1732,7 @@ __global__ __launch_bounds__(256) void k_conv_first(const IN_T* __restrict__ in,
 // Head: Conv2d(f0, 1, 1) + bias -> logit (unet.py:72,88); sigmoid; > threshold;
 // {0,255} mask (utils.py:237,241); per-frame area = #(mask>0) [inside box]
 // (features.py:238,244-245).  8 lanes per pixel, xor-shuffle reduction.
+template <bool HIN = false>
 __global__ __launch_bounds__(256) void k_head(const float* __restrict__ in, long long in_frame_stride, int in_pix_stride,
                                               const float* __restrict__ w, float bias, int Cp, int HW, int W,
                                               float threshold, const int32_t* __restrict__ boxes,
@@ -1398,6 +1758,15 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ in, long
         if (p < HW) {
             float s = 0.f;
             for (int c = cq * 4; c < Cp; c += 32) {
+                if (HIN) {   // H layout: this lane's 16-byte slot holds hi (cq < 4) or lo (cq >= 4, scaled by 2^11) of channels 8(cq&3)..+7
+                    const og_h8 hv = __builtin_bit_cast(og_h8, *(const f32x4*)(fin + (long long)p * in_pix_stride + c));
+                    const float* wp = w + (c - cq * 4) + (cq & 3) * 8;
+                    float part = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) part = fmaf((float)hv[e], wp[e], part);
+                    s += (cq < 4) ? part : part * OG_LO_INV;
+                    continue;
+                }
                 const f32x4 xv = *(const f32x4*)(fin + (long long)p * in_pix_stride + c);
                 const f32x4 wv = *(const f32x4*)(w + c);
                 s = fmaf(xv.x, wv.x, s);

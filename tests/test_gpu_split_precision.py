@@ -1,0 +1,124 @@
+"""-m gpu: the opt-in split-precision mode (`set_option("precision", 1)`: f16 hi/lo operand pairs, three
+v_mfma_f32_32x32x16_f16 per f32 product, f32 accumulation) against the SAME reference fixtures and the SAME tolerances as
+the exact-f32 default: logits abs <= 5e-5 * max(1, |ref|max); masks may differ only where the reference's own logit is within
+5e-5 of zero; the trained (zero-flip) fixture bit for bit.  It is a secondary mode: the f32 kernels stay the default."""
+import os
+
+import numpy as np
+import pytest
+
+import openglottal_amd as og
+from openglottal_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 5e-5
+
+
+def unpack(bits, h=256, w=256):
+    return np.unpackbits(bits)[: h * w].reshape(h, w)
+
+
+def make_model(sd, features, precision=1):
+    m = og.UNet(1, 1, tuple(int(f) for f in features))
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    m.set_option("precision", precision)
+    return m
+
+
+def test_every_layer_boundary_small_net_split_precision(golden_dir):
+    g = np.load(os.path.join(golden_dir, "unet_small_layers.npz"))
+    sd = synth.make_unet_state_dict(tuple(g["features"]), seed=int(g["seed"]), head_scale=float(g["head_scale"]), head_bias=float(g["head_bias"]))
+    m = make_model(sd, g["features"])
+    f = synth.random_gray_frames(1, 64, 64, seed=21)
+    logits = m((f.astype("float32") / 255.0)[:, None])
+    keys = [k[2:] for k in g.files if k.startswith("L:")]
+    assert len(keys) == 27
+    worst = 0.0
+    for k in keys:
+        ref = g["L:" + k]
+        got = logits if k == "head" else m.activation(k, 1)
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+        worst = max(worst, err)
+        assert err <= TOL, (k, err)
+    print("worst relative layer error (split precision):", worst)
+    fr = synth.random_gray_frames(3, 48, 80, seed=22)
+    assert np.abs(m((fr.astype("float32") / 255.0)[:, None]) - g["logits_48x80"]).max() <= TOL
+
+
+def test_bench_configuration_split_precision_against_reference_fixture(golden_dir):
+    import torch
+
+    g = np.load(os.path.join(golden_dir, "unet_full128.npz"))
+    feats = tuple(int(f) for f in g["features"])
+    sd = synth.make_unet_state_dict(feats, seed=int(g["seed"]), head_scale=float(g["head_scale"]), head_bias=float(g["head_bias"]))
+    m = make_model(sd, feats)
+    m.set_chunk(64)
+    frames, gt = synth.full128_frames()
+    dev = torch.device("cuda", 0)
+    fdev = torch.from_numpy(frames).to(dev)
+    area = torch.zeros(128, dtype=torch.int32, device=dev)
+    mask = torch.zeros((128, 256, 256), dtype=torch.uint8, device=dev)
+    logits = torch.zeros((128, 256, 256), dtype=torch.float32, device=dev)
+    nz = {(int(f), int(p)): float(v) for f, p, v in zip(g["near_zero_frame"], g["near_zero_pixel"], g["near_zero_logit"])}
+    for rep in range(2):   # capture, then replay of the graphs
+        m.segment_dev(fdev, 128, 256, 256, area, mask_dev=mask, logits_dev=logits)
+        m.sync()
+        mk, ar, lg = mask.cpu().numpy(), area.cpu().numpy(), logits.cpu().numpy()
+        flips_total, worst = 0, 0.0
+        for i in range(128):
+            flips = np.flatnonzero(((mk[i] > 0) != (unpack(g["masks_packed"][i]) > 0)).ravel())
+            for p in flips:
+                assert abs(nz.get((i, int(p)), 1.0)) <= TOL, (i, int(p), nz.get((i, int(p))))
+            flips_total += len(flips)
+            assert int(ar[i]) == int((mk[i] > 0).sum()) and abs(int(ar[i]) - int(g["areas"][i])) <= len(flips), i
+            e = np.abs(lg[i].ravel()[g["sample_idx"]] - g["logits_samples"][i]).max()
+            worst = max(worst, float(e))
+            assert e <= TOL, (i, e)
+        d = np.array([og.dice(mk[i], gt[i]) for i in range(80)])
+        assert np.abs(d - g["dice_vs_gt"]).max() <= 1e-3
+        print(f"split precision pass {rep}: flipped pixels {flips_total} of {128 * 65536}, max |dlogit| on the samples {worst:.3g}")
+    prof = m.profile(fdev, 64, 256, 256, reps=1)
+    kernels = [p["kernel"] for p in prof]
+    assert all(k.startswith("k_conv_mfma_h") for k in kernels), kernels      # the split-precision kernels really ran
+    # and it is a different arithmetic from the default (not a silent fall-back to the f32 kernels)
+    m.set_option("precision", 0)
+    lg32 = torch.zeros_like(logits)
+    m.segment_dev(fdev, 128, 256, 256, area, logits_dev=lg32)
+    m.sync()
+    assert not torch.equal(lg32, logits) and float((lg32 - logits).abs().max()) <= TOL
+
+
+def test_trained_zero_flip_fixture_and_small_batches_split_precision(golden_dir):
+    g = np.load(os.path.join(golden_dir, "unet_trained_small.npz"))
+    sd = {k[2:]: g[k] for k in g.files if k.startswith("W:")}
+    m = make_model(sd, g["features"])
+    frames, gt = synth.glottis_frames(4, 20, seed=99)
+    ref_masks = np.stack([unpack(b) for b in g["masks_packed"]])
+    for chunk in (32, 1, 3):      # full launches (fused first layer / head) and small ones (separate first-layer and head kernels)
+        m.set_chunk(chunk)
+        masks, areas, _ = m.segment(frames)
+        assert np.array_equal(masks > 0, ref_masks > 0), chunk                   # every one of 80 * 65536 pixels
+        assert np.array_equal(areas.astype(np.int64), g["areas"]), chunk          # area waveform integers bit-exact
+    boxes = np.array([og.utils.normalize_box((100, 80, 160, 200), 256, 256)] * 8, np.int32)
+    _, a, _ = m.segment(frames[:8], boxes=boxes, want_mask=False)
+    assert a.tolist() == [int((ref_masks[i][80:200, 100:160] > 0).sum()) for i in range(8)]
+
+
+def test_odd_shapes_and_padded_channels_split_precision():
+    from oracle import unet_oracle as O
+    for feats, B, H, W, seed in [((32, 64, 128), 96, 80, 48, 321), ((33, 66), 128, 32, 64, 99), ((6, 12, 24), 2, 48, 32, 5)]:
+        sd = synth.make_unet_state_dict(feats, seed=seed, head_scale=2.0, head_bias=-0.4)
+        m = make_model(sd, feats)
+        m.set_chunk(B)
+        fr = synth.random_gray_frames(B, H, W, seed=17)
+        masks, areas, logits = m.segment(fr, want_logits=True)
+        masks2, areas2, logits2 = m.segment(fr, want_logits=True)
+        assert np.array_equal(logits, logits2) and np.array_equal(areas, areas2)          # repeatable
+        ref_mask, ref_logits = O.segment_frames(sd, fr[:4], backend="torch")
+        scale = max(1.0, np.abs(ref_logits).max())
+        assert np.abs(logits[:4] - ref_logits).max() <= TOL * scale, (feats, np.abs(logits[:4] - ref_logits).max())
+        assert np.all(np.abs(ref_logits[(masks[:4] > 0) != (ref_mask > 0)]) <= TOL * scale)
+        assert np.array_equal(areas, (masks > 0).reshape(B, -1).sum(1))
