@@ -34,6 +34,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, den
 PEAK_HBM_BYTES = 8.0e12
 LAYER_BOUNDARY_BYTES_PER_FRAME = 183.5e6  # every layer reads its inputs once and writes its output once, fp32
 DOMINANT = "k_conv_mfma_o<2,0,16>"  # the 64-column 3x3 conv on 16x16 tiles: largest share of chain time
+PEAK_F16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense f16/bf16 MFMA; the split-precision mode spends 3 f16 MFMA FLOPs per f32 FLOP
 
 
 def host_cores() -> int:
@@ -145,6 +146,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-inclusive", action="store_true")
+    ap.add_argument("--no-split-precision", action="store_true", help="skip the exploratory split-precision leg")
     args = ap.parse_args()
 
     import torch
@@ -266,24 +268,53 @@ def main() -> None:
         fence(); e1 = time.perf_counter() - t1
         out["latency_mode"] = {"frames_per_launch": 1, "value": round(n1 / e1, 1), "unit": "frames/s", "frames": n1}
         model.set_chunk(args.chunk)
-    if world == 1 and F and not args.no_roofline:
+    def roofline(kernel_prefix, peak_equiv, note=None):
+        """Dominant kernel (largest share of chain time among kernels starting with `kernel_prefix`) from HIP events around
+        every launch of one eager chain; `achieved` = algorithmic (f32-equivalent) FLOPs of its launches / their time."""
         B = min(args.chunk, F)
         prof = model.profile(frames, B, 256, 256, reps=max(3, min(20, args.steps)))
-        dom = [p for p in prof if p["kernel"] == DOMINANT]
+        per = {}
+        for p in prof:
+            per[p["kernel"]] = per.get(p["kernel"], 0.0) + p["ms"]
+        name = max((k for k in per if k.startswith(kernel_prefix)), key=lambda k: per[k])
+        dom = [p for p in prof if p["kernel"] == name]
         fl, ms = sum(p["flops"] for p in dom), sum(p["ms"] for p in dom)
         tot_ms = sum(p["ms"] for p in prof)
         ach = fl / (ms * 1e-3) / 1e12
-        tr = pmc_traffic(DOMINANT, B)   # HBM bytes per launch from the committed rocprofv3 PMC passes (or None)
-        out["roofline"] = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                           "traffic": (tr or {}).get("hbm_bytes_per_launch") if (tr or {}).get("same_kernels") else None,
-                           "traffic_detail": tr,
-                           "launches_per_chain": len(dom), "avg_launch_ms": round(ms / len(dom), 4),
-                           "share_of_chain_time": round(ms / tot_ms, 3), "frames_per_launch": B,
-                           "chain_ms": round(tot_ms, 3), "kernel_source_sha": kernel_source_sha()}
-        out["per_kernel_ms"] = {}
-        for p in prof:
-            out["per_kernel_ms"][p["kernel"]] = round(out["per_kernel_ms"].get(p["kernel"], 0.0) + p["ms"], 4)
+        tr = pmc_traffic(name, B)   # HBM bytes per launch from the committed rocprofv3 PMC passes (or None)
+        r = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak_equiv,
+             "unit": "TFLOP/s", "frac": round(ach / peak_equiv, 4),
+             "traffic": (tr or {}).get("hbm_bytes_per_launch") if (tr or {}).get("same_kernels") else None,
+             "traffic_detail": tr, "launches_per_chain": len(dom), "avg_launch_ms": round(ms / len(dom), 4),
+             "share_of_chain_time": round(ms / tot_ms, 3), "frames_per_launch": B, "chain_ms": round(tot_ms, 3),
+             "kernel_source_sha": kernel_source_sha()}
+        if note:
+            r["note"] = note
+        return r, {k: round(v, 4) for k, v in per.items()}
+
+    if world == 1 and F and not args.no_roofline:
+        out["roofline"], out["per_kernel_ms"] = roofline("k_conv_mfma_", PEAK_F32_MFMA_TFLOPS if not any(o.startswith("precision=1") for o in args.option) else round(PEAK_F16_MFMA_TFLOPS / 3, 1))
+    if world == 1 and F and not args.no_split_precision and not any(o.startswith("precision=") for o in args.option):
+        # Exploratory secondary mode, NEVER the headline: f16 hi/lo operand pairs, 3 x v_mfma_f32_32x32x16_f16 per f32 product,
+        # f32 accumulation; passes the same reference fixtures at the same tolerance (tests/test_gpu_split_precision.py)
+        model.set_option("precision", 1)
+        for _ in range(args.warmup):
+            step()
+        fence(); t1 = time.perf_counter()
+        for _ in range(args.steps):
+            w2 = step()
+        fence(); e2 = time.perf_counter() - t1
+        fps2 = args.steps * n_total / e2
+        flips = int((w2 != wave).sum())
+        rl, per = roofline("k_conv_mfma_h", round(PEAK_F16_MFMA_TFLOPS / 3, 1),
+                           "achieved = algorithmic f32-equivalent FLOP/s; peak = dense f16 MFMA peak / 3 (three f16 MFMAs per f32 product); "
+                           "the bare 3-MFMA loop on random data sustains 454-526 of it (tools/ubench/mfma_f16_split)")
+        out["split_precision"] = {"value": round(fps2, 1), "unit": "frames/s", "vs_f32_path": round(fps2 / fps, 3), "dtype": "f16 hi/lo x3 MFMA, f32 accumulate",
+                                  "ms_per_step": round(1e3 * e2 / args.steps, 3), "tflops_f32_equivalent": round(fps2 * model.flops_per_frame(256, 256) / 1e12, 2),
+                                  "frames_whose_area_differs_from_f32_path": flips,
+                                  "chain_frac_hbm_layer_boundary_model": round(fps2 * LAYER_BOUNDARY_BYTES_PER_FRAME / PEAK_HBM_BYTES, 4),
+                                  "roofline": rl, "per_kernel_ms": per}
+        model.set_option("precision", 0)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sd)
     if rank == 0:
