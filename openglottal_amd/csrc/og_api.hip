@@ -557,6 +557,7 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<1, 0, 8, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                conv_o_lds<1, 0, 8>() + (12 * 20 + 352) * 4));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<2, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 16>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<1, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 16>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<2, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<1, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<2, 1, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 1, 8>()));
@@ -637,7 +638,10 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     a.partial = h->d_partial;
     a.tile_counter = (h->splitk_fused && h->d_tile_counter) ? h->d_tile_counter : nullptr;
     if (h->precision == 1) {   // opt-in split precision: always the occupancy-shaped kernel, no split-K
-        if (a.head_w != nullptr) big = false;
+        // tile height: an MFMA step is 5x shorter here than in the f32 kernels, so barriers and staged bytes per MFMA weigh
+        // more: 16-row tiles wherever they tile the image ("tile_h" 8 forces 8 rows, 16 / 0 = this rule)
+        big = full16 && h->tile_h != 8;
+        if (a.head_w != nullptr) big = false;   // per-tile count slots of the fused head are laid out for 8x16 tiles
         const int th_h = big ? 16 : 8;
         a.tiles_y = (in.H + th_h - 1) / th_h;
         a.n_spatial = B * a.tiles_x * a.tiles_y;
@@ -649,14 +653,10 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
             if (out.H != in.H || out.W != in.W) return fail(OG_EINVAL, "conv shape mismatch");
             const int n_ntiles = L.Cout_p / (32 * L.NT);
             const double fl = 2.0 * px_h * 9.0 * L.Cin * L.Cout;
-            if (big && L.NT == 2) {
-                prof_begin(h, L.name, "k_conv_mfma_h<2,0,16>", fl);
-                rc_h = launch_conv_h<2, 0, 16, 2>(ctx, a, n_ntiles);
+            if (big) {
+                prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma_h<2,0,16>" : "k_conv_mfma_h<1,0,16>", fl);
+                rc_h = (L.NT == 2) ? launch_conv_h<2, 0, 16, 2>(ctx, a, n_ntiles) : launch_conv_h<1, 0, 16, 2>(ctx, a, n_ntiles);
             } else {
-                if (big) {   // 16-row tiles exist for the 64-column kernel only
-                    a.tiles_y = (in.H + 7) / 8;
-                    a.n_spatial = B * a.tiles_x * a.tiles_y;
-                }
                 prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma_h<2,0,8>" : "k_conv_mfma_h<1,0,8>", fl);
                 rc_h = (L.NT == 2) ? launch_conv_h<2, 0, 8, 3>(ctx, a, n_ntiles) : launch_conv_h<1, 0, 8, 3>(ctx, a, n_ntiles);
             }
