@@ -1142,10 +1142,15 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
     };
 
     // first halo and weights are on their way before the rest of the set-up (which then hides their latency)
+    // Weight slices are staged TWO steps ahead in the 3-stage ring (MODE 0): a step is ~5x shorter than in the f32 kernel
+    // (24 MFMAs of 32 cycles per wave at most), less than the latency of the LDS-DMA that has to land before the next step.
+    constexpr int WAHEAD = (NSTG == 3) ? 2 : 1;
+    const int n_steps_total = (MODE == 3) ? total_steps : a.n_chunks * TAPS;
     if (!FIRST) {
         if (st != nullptr && tid == 0) st[6] = __builtin_amdgcn_s_memtime();
         stage_halo(0, c_lo);
         stage_w((NSTG == 3) ? s_lo % 3 : (s_lo & 1), s_lo);
+        if (WAHEAD == 2 && s_lo + 1 < n_steps_total) stage_w((s_lo + 1) % 3, s_lo + 1);
     }
 
     // ---- fragment addressing ----
@@ -1205,6 +1210,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
         }
         for (int i = tid; i < 352; i += 256) fw[i] = (i < 288) ? a.first_w9[i] : (i < 320 ? a.first_scale[i - 288] : a.first_shift[i - 320]);
         stage_w(0, 0);
+        if (WAHEAD == 2 && 1 < n_steps_total) stage_w(1, 1);
         __syncthreads();
         // one item = (halo pixel, 8-channel group L): the fma chain of k_conv_first for 8 channels, then hi -> slot L, lo -> slot 4+L
         for (int q = tid; q < HALO_PIX * 4; q += 256) {
@@ -1255,8 +1261,9 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
                 const int par = c / cpc;
                 if (((t >> 1) == 0 && (par & 2) == 0) || ((t & 1) == 0 && (par & 1) == 0)) continue;
             }
-            const int stg = (NSTG == 3) ? t % 3 : (step & 1), stg_next = (NSTG == 3) ? (t + 1) % 3 : ((step + 1) & 1);
-            if (step + 1 < step_end) stage_w(stg_next, step + 1);
+            const int stg = (NSTG == 3) ? t % 3 : (step & 1), stg_next = (NSTG == 3) ? (t + WAHEAD) % 3 : ((step + 1) & 1);
+            const bool more = (step + WAHEAD < step_end);
+            if (more) stage_w(stg_next, step + WAHEAD);
 
             const unsigned wb = (unsigned)stg * WBYTES;
             const int dy = (MODE == 0) ? t / 3 : (MODE == 3) ? (t >> 1) : 0;
@@ -1278,7 +1285,9 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
                     cor[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(og_h8, av[2 + t2]), __builtin_bit_cast(og_h8, bv[t2]), cor[m], 0, 0, 0);
                 }
             }
-            og_wait_dma();
+            // the NEXT step's slice must have landed; the one staged just now (NT instructions per wave) may stay in flight
+            if (WAHEAD == 2 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT) : "memory");
+            else og_wait_dma();
             __syncthreads();
             ++step;
         }

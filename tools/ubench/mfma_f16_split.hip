@@ -46,6 +46,40 @@ __global__ __launch_bounds__(256) void k_rate(float* out, int iters, const h8* s
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// (2b): the conv kernel's mix: per 24 MFMAs (4 sub-tiles x 6), 4 B-fragment + 16 A-fragment ds_read_b128 of random data
+__global__ __launch_bounds__(256) void k_rate_lds(float* out, int iters, const h8* src) {
+    __shared__ h8 lds[4096];   // 64 KB
+    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = src[i & 1023];
+    __syncthreads();
+    f32x16 acc[4], cor[4];
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; cor[i][r] = 0.f; }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int off = w * 1024 + lane;
+    for (int it = 0; it < iters; ++it) {
+        h8 bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = lds[(off + 64 * j) & 4095];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            h8 av[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av[j] = lds[(off + 256 + 64 * (4 * m + j)) & 4095];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[t], bv[t], acc[m], 0, 0, 0);
+                cor[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[t], bv[2 + t], cor[m], 0, 0, 0);
+                cor[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[2 + t], bv[t], cor[m], 0, 0, 0);
+            }
+        }
+        off = (off + 1344) & 4095;
+    }
+    float s = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) s += acc[i][r] + cor[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 // (3): one 32x32 tile, K = 4608: split product vs double reference
 __global__ void k_exact(const float* A, const float* B, int K, float* D_split, float* D_single) {   // A [32][K], B [K][32]
     const int l = threadIdx.x, r = l & 31, h = l >> 5;
@@ -91,6 +125,18 @@ int main() {
         const double mfma = (double)grid * 4 * iters * 2 * 3;
         printf("(2) 3 MFMA(32x32x16 f16)/step, %d wave(s)/SIMD, random data: %.1f TFLOP/s raw f16 = %.1f TFLOP/s of f32-equivalent products (x%.2f of 157.3)\n",
                wg, mfma * 32768 / ms / 1e9, mfma / 3 * 32768 / ms / 1e9, mfma / 3 * 32768 / ms / 1e9 / 157.3);
+    }
+    for (int wg = 1; wg <= 2; ++wg) {
+        const int iters = 2000, grid = 256 * wg;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(k_rate_lds, dim3(grid), dim3(256), 0, 0, out, iters, src);
+            hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        }
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double mfma = (double)grid * 4 * iters * 24;
+        printf("(2b) same with the conv kernel's LDS traffic (20 ds_read_b128 per 24 MFMAs), %d wave(s)/SIMD: %.1f TFLOP/s raw f16 = %.1f f32-equivalent\n",
+               wg, mfma * 32768 / ms / 1e9, mfma / 3 * 32768 / ms / 1e9);
     }
     // (3)
     const int K = 4608;
