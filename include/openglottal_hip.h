@@ -141,6 +141,11 @@ void* og_unet_stream(og_unet* h);          /* hipStream_t the handle launches on
 
 /* Micro-batch the frame loop uses per kernel chain (default 32); >=1. */
 int og_unet_set_chunk(og_unet* h, int frames_per_launch);
+/* Allocate the activation arenas of every lane for micro-batches of up to `frames_per_launch` frames of H x W ahead of
+ * time.  Optional: the entry points grow them on demand (one hipFree/hipMalloc + graph re-capture when a call needs more
+ * bytes than any before it); calls at other frame sizes or smaller micro-batches re-plan inside the existing allocation and
+ * keep their captured graphs, so reserving the largest shape once makes a mixed-size stream allocation-free. */
+int og_unet_reserve(og_unet* h, int frames_per_launch, int H, int W);
 /* 1 = replay captured hipGraphs for repeated shapes (default), 0 = eager launches. */
 int og_unet_set_graphs(og_unet* h, int enable);
 

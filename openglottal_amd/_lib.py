@@ -58,6 +58,7 @@ PROTOTYPES = {
     "og_bgr2gray_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "og_unet_sync": (C.c_int, [C.c_void_p]),
     "og_unet_stream": (C.c_void_p, [C.c_void_p]),
+    "og_unet_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "og_unet_set_chunk": (C.c_int, [C.c_void_p, C.c_int]),
     "og_unet_set_graphs": (C.c_int, [C.c_void_p, C.c_int]),
     "og_unet_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),

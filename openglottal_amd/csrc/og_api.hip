@@ -59,7 +59,7 @@ struct Act {  // NHWC activation view
 };
 
 struct GraphKey {
-    int B, H, W, flags;
+    int B, H, W, flags, capB;   // capB: frame capacity of the arena plan the graph's pointers belong to
     bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
 };
 
@@ -86,6 +86,7 @@ struct og_unet {
     // activation arena for (capB, H, W)
     int capB = 0, aH = 0, aW = 0;
     void* arena = nullptr;
+    size_t arena_bytes = 0;
     std::vector<Act> A, CAT, P, UA, UB;
     Act BA, BB;
 
@@ -333,20 +334,17 @@ void drop_graphs(og_unet* h) {
     h->graphs.clear();
 }
 
+// Activation arena.  Capacity is kept in BYTES: a call at another frame size (or a smaller micro-batch) re-plans the layer
+// buffers inside the existing allocation instead of freeing and reallocating it, and captured hipGraphs stay valid as long as
+// the allocation does (their key carries the plan's frame capacity), so a stream of mixed frame sizes does not thrash
+// hipMalloc / graph capture.  Growth still reallocates once; og_unet_reserve() does it ahead of time.
 int ensure_arena(og_unet* h, int B, int H, int W) {
-    if (h->arena && B <= h->capB && H == h->aH && W == h->aW) return OG_OK;
-    drop_graphs(h);
-    if (h->arena) {
-        HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipFree(h->arena));
-        h->arena = nullptr;
-    }
+    const bool same_shape = (H == h->aH && W == h->aW);
+    if (h->arena && same_shape && B <= h->capB) return OG_OK;
+    if (same_shape && B < h->capB) B = h->capB;
     const int L = h->L;
-    h->A.assign(L, Act());
-    h->CAT.assign(L, Act());
-    h->P.assign(L, Act());
-    h->UA.assign(L, Act());
-    h->UB.assign(L, Act());
+    std::vector<Act> A(L), CAT(L), P(L), UA(L), UB(L);
+    Act BA, BB;
     size_t total = 0;
     auto plan = [&](Act& a, int C, int hh, int ww) {
         a.C = C;
@@ -358,29 +356,46 @@ int ensure_arena(og_unet* h, int B, int H, int W) {
     for (int i = 0; i < L; ++i) {
         const int C = cp32(h->features[i]);
         const int hh = H >> i, ww = W >> i;
-        plan(h->A[i], C, hh, ww);
-        plan(h->CAT[i], 2 * C, hh, ww);
-        plan(h->P[i], C, hh >> 1, ww >> 1);
-        plan(h->UA[i], C, hh, ww);
-        plan(h->UB[i], C, hh, ww);
+        plan(A[i], C, hh, ww);
+        plan(CAT[i], 2 * C, hh, ww);
+        plan(P[i], C, hh >> 1, ww >> 1);
+        plan(UA[i], C, hh, ww);
+        plan(UB[i], C, hh, ww);
     }
     const int Cb = cp32(2 * h->features[L - 1]);
-    plan(h->BA, Cb, H >> L, W >> L);
-    plan(h->BB, Cb, H >> L, W >> L);
-    HIPCHK(hipMalloc(&h->arena, total));
-    // Padded channels of the convT half etc. are always written (zero weights ->
-    // exact zeros), but clear once so debug reads of never-touched bytes are defined.
+    plan(BA, Cb, H >> L, W >> L);
+    plan(BB, Cb, H >> L, W >> L);
+    if (h->stream) HIPCHK(hipStreamSynchronize(h->stream));   // the old plan may still be in use
+    if (!h->arena || total > h->arena_bytes) {
+        drop_graphs(h);   // they hold pointers into the old allocation
+        if (h->arena) {
+            HIPCHK(hipFree(h->arena));
+            h->arena = nullptr;
+            h->arena_bytes = 0;
+        }
+        HIPCHK(hipMalloc(&h->arena, total));
+        h->arena_bytes = total;
+    }
+    // Padded channels of the convT half etc. are always written (zero weights -> exact zeros), but clear on every re-plan
+    // so that debug reads of never-touched bytes are defined.
     HIPCHK(hipMemsetAsync(h->arena, 0, total, h->stream));
     auto fix = [&](Act& a) { a.p = (float*)((char*)h->arena + (size_t)a.p); };
     for (int i = 0; i < L; ++i) {
-        fix(h->A[i]);
-        fix(h->CAT[i]);
-        fix(h->P[i]);
-        fix(h->UA[i]);
-        fix(h->UB[i]);
+        fix(A[i]);
+        fix(CAT[i]);
+        fix(P[i]);
+        fix(UA[i]);
+        fix(UB[i]);
     }
-    fix(h->BA);
-    fix(h->BB);
+    fix(BA);
+    fix(BB);
+    h->A = A;
+    h->CAT = CAT;
+    h->P = P;
+    h->UA = UA;
+    h->UB = UB;
+    h->BA = BA;
+    h->BB = BB;
     h->capB = B;
     h->aH = H;
     h->aW = W;
@@ -962,6 +977,7 @@ int run_chunk(og_unet* h, int kind, const void* in, int B, int H, int W, float t
         key.H = H;
         key.W = W;
         key.flags = (fuse ? 1 : 0) | (ff ? 2 : 0) | (h->precision ? 4 : 0);
+        key.capB = h->capB;
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
             hipGraph_t g = nullptr;
@@ -1369,6 +1385,15 @@ int og_unet_finalize(og_unet* h) {
     return OG_OK;
 }
 
+int og_unet_reserve(og_unet* h, int frames_per_launch, int H, int W) {
+    int rc = check_shape(h, frames_per_launch, H, W);
+    if (rc) return rc;
+    if (frames_per_launch < 1) return fail(OG_EINVAL, "frames_per_launch must be >= 1");
+    for (og_unet* t = h; t; t = t->twin)
+        if ((rc = ensure_arena(t, frames_per_launch, H, W))) return rc;
+    return OG_OK;
+}
+
 int og_unet_set_chunk(og_unet* h, int n) {
     if (!h || n < 1 || n > 4096) return fail(OG_EINVAL, "chunk must be in 1..4096");
     h->chunk = n;
@@ -1448,7 +1473,7 @@ int og_unet_segment_u8_dev(og_unet* h, const uint8_t* gray, int B, int H, int W,
     if (B == 0) return OG_OK;
     const int chunk = effective_chunk(h);
     const int cb = chunk < B ? chunk : B;
-    if ((rc = ensure_arena(h, cb > h->capB ? cb : h->capB, H, W))) return rc;
+    if ((rc = ensure_arena(h, cb, H, W))) return rc;
     if (area) HIPCHK(hipMemsetAsync(area, 0, (size_t)B * sizeof(int32_t), h->stream));
     const size_t HW = (size_t)H * W;
     const int n_chunks = (B + chunk - 1) / chunk;
@@ -1459,7 +1484,7 @@ int og_unet_segment_u8_dev(og_unet* h, const uint8_t* gray, int B, int H, int W,
     if (h->dual)
         for (og_unet* t = h->twin; t && n_lanes < want && n_lanes < n_chunks; t = t->twin) lanes[n_lanes++] = t;
     for (int l = 1; l < n_lanes; ++l)   // every allocation BEFORE the fork: nothing below can fail between fork and join except a launch
-        if ((rc = ensure_arena(lanes[l], cb > lanes[l]->capB ? cb : lanes[l]->capB, H, W))) return rc;
+        if ((rc = ensure_arena(lanes[l], cb, H, W))) return rc;
     if (n_lanes > 1) HIPCHK(hipEventRecord(h->ev_fork, h->stream));
     int forked = 1;
     for (int l = 1; l < n_lanes && !rc; ++l) {  // a lane's chain must see everything enqueued so far on this stream (area memset, caller's H2D copies)
@@ -1505,7 +1530,7 @@ static int stream_impl(og_unet* h, const uint8_t* frames, int B, int H, int W, i
     if (h->dual)
         for (og_unet* t = h->twin; t && n_lanes < want && n_lanes < n_chunks; t = t->twin) lanes[n_lanes++] = t;
     for (int l = 0; l < n_lanes; ++l)
-        if ((rc = ensure_arena(lanes[l], cb > lanes[l]->capB ? cb : lanes[l]->capB, H, W))) return rc;
+        if ((rc = ensure_arena(lanes[l], cb, H, W))) return rc;
     const int n_slots = (n_chunks < n_lanes + 2) ? n_chunks : n_lanes + 2;   // one being filled, one per lane computing, one draining
     if ((rc = ensure_ring(h, n_slots, cb, H, W, ch, mask != nullptr, logits != nullptr))) return rc;
     auto& R = h->ring;
@@ -1621,7 +1646,7 @@ int og_unet_forward_f32(og_unet* h, const float* x, int B, int H, int W, float* 
     HIPCHK(hipMemcpyAsync(s + o_in, x, B * HW * 4, hipMemcpyHostToDevice, h->stream));
     const int chunk = effective_chunk(h);
     const int cb = chunk < B ? chunk : B;
-    if ((rc = ensure_arena(h, cb > h->capB ? cb : h->capB, H, W))) return rc;
+    if ((rc = ensure_arena(h, cb, H, W))) return rc;
     const int taps_saved = h->keep_taps;
     h->keep_taps = 1;  // the parity/debug entry point keeps every layer-boundary tensor readable
     for (int b0 = 0; b0 < B && !rc; b0 += chunk) {
@@ -1846,7 +1871,7 @@ int og_unet_profile(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, in
     if (rc) return rc;
     if (!gray_dev || B < 1 || reps < 1 || !layers || !kernels || !ms || !flops || !n_entries)
         return fail(OG_EINVAL, "bad argument");
-    if ((rc = ensure_arena(h, B > h->capB ? B : h->capB, H, W))) return rc;
+    if ((rc = ensure_arena(h, B, H, W))) return rc;
     if ((rc = ensure_stage(h, al256((size_t)B * 4)))) return rc;
     std::vector<double> acc;
     std::vector<og_unet::ProfEntry> first;
@@ -1891,7 +1916,7 @@ int og_unet_clock_probe(og_unet* h, const uint8_t* gray_dev, int B, int H, int W
     int rc = check_shape(h, B, H, W);
     if (rc) return rc;
     if (!gray_dev || !mhz || !n_entries || B < 1) return fail(OG_EINVAL, "bad argument");
-    if ((rc = ensure_arena(h, B > h->capB ? B : h->capB, H, W))) return rc;
+    if ((rc = ensure_arena(h, B, H, W))) return rc;
     if ((rc = ensure_stage(h, al256((size_t)B * 4)))) return rc;
     const size_t nst = (size_t)64 * 1024 * 4;
     if (!h->d_stamps) HIPCHK(hipMalloc((void**)&h->d_stamps, nst * 8));

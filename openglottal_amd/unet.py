@@ -226,6 +226,12 @@ class UNet:
         self._require()
         check(lib().og_unet_sync(self._h), "og_unet_sync")
 
+    def reserve(self, frames_per_launch: int, H: int = 256, W: int = 256) -> None:
+        """Pre-allocate the activation arenas (all lanes) for micro-batches of this size: later calls at this or any
+        smaller footprint (other frame sizes included) neither allocate nor re-capture graphs."""
+        self._require()
+        check(lib().og_unet_reserve(self._h, int(frames_per_launch), int(H), int(W)), "og_unet_reserve")
+
     def set_chunk(self, frames_per_launch: int) -> None:
         self._require()
         check(lib().og_unet_set_chunk(self._h, int(frames_per_launch)), "og_unet_set_chunk")

@@ -204,3 +204,32 @@ def test_streaming_keeps_device_memory_bounded_for_a_long_video(trained, tmp_pat
     free1, _ = torch.cuda.mem_get_info()
     assert np.array_equal(wave.astype(np.int64), g["areas"][idx])
     assert free0 - free1 < 64 << 20, (free0, free1)   # nothing proportional to 6 000 frames (393 MB) was allocated
+
+
+def test_mixed_frame_sizes_reuse_the_arena_and_give_the_same_results(trained):
+    """A stream of mixed frame sizes re-plans the activation arena in place (capacity is kept in bytes; og_unet_reserve
+    allocates it ahead of time): no allocation after the reserve, results equal to those of a fresh handle per size."""
+    import torch
+
+    g, m, frames = trained
+    m.set_chunk(16)
+    m.reserve(16, 256, 256)
+    shapes = [(256, 256), (64, 128), (256, 256), (128, 128), (48, 80), (256, 256), (64, 128)]
+    rs = np.random.RandomState(8)
+    inputs = [frames[:20] if s == (256, 256) else rs.randint(0, 256, (20,) + s, dtype=np.uint8) for s in shapes]
+    m.segment(inputs[0]); m.segment(inputs[1])     # ring buffers of the streaming engine exist for both footprints now
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    got = [m.segment(x, want_logits=True) for x in inputs]
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 48 << 20, (free0, free1)     # only ring slots for new (smaller) footprints, never an arena
+    for s, x, (mk, ar, lg) in zip(shapes, inputs, got):
+        fresh = og.UNet(1, 1, m.features)
+        fresh.load_state_dict(m.state_dict())
+        fresh.to("cuda:0").eval()
+        fresh.set_chunk(16)
+        mk2, ar2, lg2 = fresh.segment(x, want_logits=True)
+        assert np.array_equal(mk, mk2) and np.array_equal(ar, ar2) and np.array_equal(lg, lg2), s
+    assert np.array_equal(got[0][1].astype(np.int64), g["areas"][:20])
+    m.set_chunk(32)
