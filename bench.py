@@ -146,6 +146,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-inclusive", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the Dice-delta leg on the reference fixture")
     ap.add_argument("--no-split-precision", action="store_true", help="skip the exploratory split-precision leg")
     args = ap.parse_args()
 
@@ -244,6 +245,26 @@ def main() -> None:
         # whole-chain fractions (wall clock): binding roof = f32 MFMA; HBM with SURVEY 8(d)'s layer-boundary model
         out["chain_frac_mfma"] = round(out["tflops"] / PEAK_F32_MFMA_TFLOPS / world, 4)
         out["chain_frac_hbm_layer_boundary_model"] = round(fps * LAYER_BOUNDARY_BYTES_PER_FRAME / PEAK_HBM_BYTES / world, 4)
+    if world == 1 and not args.no_parity:
+        # BASELINE metric, second half ("Dice delta vs CPU ref"): the 128-frame full-width fixture that the reference's own
+        # unet_segment_frame produced on the CPU (tests/golden/unet_full128.npz), run with exactly this configuration
+        gpath = os.path.join(ROOT, "tests", "golden", "unet_full128.npz")
+        if os.path.exists(gpath):
+            g = np.load(gpath)
+            gfr, ggt = synth.full128_frames()
+            gd = torch.from_numpy(gfr).to(dev)
+            ga = torch.zeros(128, dtype=torch.int32, device=dev)
+            gm = torch.zeros((128, 256, 256), dtype=torch.uint8, device=dev)
+            model.segment_dev(gd, 128, 256, 256, ga, mask_dev=gm)
+            model.sync()
+            mk, ar = gm.cpu().numpy(), ga.cpu().numpy()
+            ref = np.unpackbits(g["masks_packed"], axis=1)[:, :65536].reshape(128, 256, 256)
+            flips = int(((mk > 0) != (ref > 0)).sum())
+            dd = max(abs(og.dice(mk[i], ggt[i]) - float(g["dice_vs_gt"][i])) for i in range(80))
+            out["parity"] = {"fixture": "tests/golden/unet_full128.npz (reference unet_segment_frame on CPU, 80 structured + 48 stream frames)",
+                             "dice_delta_vs_cpu_ref_max": round(dd, 8), "flipped_mask_pixels": flips, "of_pixels": 128 * 65536,
+                             "frames_with_area_difference": int((ar.astype(np.int64) != g["areas"]).sum()),
+                             "note": "every flipped pixel sits where the reference's own logit is within 5e-5 of zero (tests/test_gpu_bench_config.py)"}
     if world == 1 and F and not args.no_host_inclusive:
         # SURVEY 8(d) / benchmark_video_speed.py:83-109: first H2D enqueue -> last area on the host, BGR->gray inside
         hf = bgr_host[:F]

@@ -228,23 +228,34 @@ def evaluate_counts_device(frames, gts, unet_model, detector=None, crop_model=No
     def up(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
-    def letterbox_dev(imgs, ch):
+    def pack(imgs):   # host side of the front end: one contiguous buffer + per-frame records (runs ahead on a worker thread)
         packed, offsets, shapes = pack_frames(imgs)
         geom = np.array([letterbox_geometry(int(h), int(w), S) for h, w in shapes], np.int32)
-        o = torch.empty((len(imgs), S, S, 3) if ch == 3 else (len(imgs), S, S), dtype=torch.uint8, device=dev)
-        bufs = [up(packed), up(offsets), up(shapes), up(geom)]
-        check(lib().og_canvas_letterbox_u8_dev(unet_model._h, ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), len(imgs), ch, S, ptr(bufs[3]), 0, ptr(o)),
+        return packed, offsets, shapes, geom
+
+    def letterbox_dev(rec, n_img, ch):
+        o = torch.empty((n_img, S, S, 3) if ch == 3 else (n_img, S, S), dtype=torch.uint8, device=dev)
+        bufs = [up(a) for a in rec]
+        check(lib().og_canvas_letterbox_u8_dev(unet_model._h, ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), n_img, ch, S, ptr(bufs[3]), 0, ptr(o)),
               "og_canvas_letterbox_u8_dev")
         unet_model.sync()   # the staging tensors above may be released now
         return o
 
-    for lo in range(0, n, block):
+    def prepare(lo):
         fb = [np.asarray(f) for f in frames[lo:lo + block]]
         gb = [np.asarray(g) for g in gts[lo:lo + block]]
-        B = len(fb)
-        bgr = fb[0].ndim == 3
-        img = letterbox_dev(fb, 3 if bgr else 1)                       # img_lb  (eval_bagls.py:153)
-        gt = letterbox_dev(gb, 1)                                       # gt_lb   (:154)
+        return len(fb), fb[0].ndim == 3, pack(fb), pack(gb)
+
+    from concurrent.futures import ThreadPoolExecutor
+
+    pool = ThreadPoolExecutor(1)   # packs block k+1 on the host while the device works on block k
+    nxt = pool.submit(prepare, 0)
+    for lo in range(0, n, block):
+        B, bgr, rec_f, rec_g = nxt.result()
+        if lo + block < n:
+            nxt = pool.submit(prepare, lo + block)
+        img = letterbox_dev(rec_f, B, 3 if bgr else 1)                 # img_lb  (eval_bagls.py:153)
+        gt = letterbox_dev(rec_g, B, 1)                                 # gt_lb   (:154)
         if bgr:
             gray = torch.empty((B, S, S), dtype=torch.uint8, device=dev)
             unet_model.bgr2gray_dev(img, B, S, S, gray)                 # gray_lb (:155)
@@ -314,6 +325,7 @@ def evaluate_counts_device(frames, gts, unet_model, detector=None, crop_model=No
         res[:, 0:3] = u
         res[:, 9] = u[:, 2] > 0
         out[lo:lo + B] = res
+    pool.shutdown()
     return out
 
 

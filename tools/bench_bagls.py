@@ -19,8 +19,15 @@ E.evaluate_device(frames[:256], gts[:256], m, det, cm)          # warm-up: arena
 t0 = time.perf_counter()
 agg, st = E.evaluate_device(frames, gts, m, det, cm)
 el = time.perf_counter() - t0
+m.set_option("precision", 1); cm.set_option("precision", 1)     # secondary: the same loop on the split-precision kernels
+E.evaluate_device(frames[:256], gts[:256], m, det, cm)
+t0 = time.perf_counter()
+agg2, st2 = E.evaluate_device(frames, gts, m, det, cm)
+el2 = time.perf_counter() - t0
+dd = {p: float(np.abs(np.array(agg[p]["dice"]) - np.array(agg2[p]["dice"])).max()) for p in agg}
 out = sys.argv[2] if len(sys.argv) > 2 else os.path.join("gpurun_out", "bagls_eval_standin.json")
 E.dump_json(out, agg, st, meta={"bagls_dir": "synthetic stand-in (synth.bagls_standin), random-init weights", "frames": n})
 print(json.dumps({"pipeline": "C5 BAGLS evaluation loop, 3 pipelines, mixed frame sizes, all on the device", "frames": n,
                   "frames_per_s": round(n / el, 1), "seconds": round(el, 2), "generate_s": round(t_gen, 1),
-                  "summary": E.summarize(agg), "det_stats": st, "bytes_back_per_frame": 40}))
+                  "summary": E.summarize(agg), "det_stats": st, "bytes_back_per_frame": 40,
+                  "split_precision": {"frames_per_s": round(n / el2, 1), "max_abs_per_frame_dice_difference_vs_f32": dd, "det_stats": st2}}))
