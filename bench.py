@@ -33,7 +33,6 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = f32 vector peak
 PEAK_HBM_BYTES = 8.0e12
 LAYER_BOUNDARY_BYTES_PER_FRAME = 183.5e6  # every layer reads its inputs once and writes its output once, fp32
-DOMINANT = "k_conv_mfma_o<2,0,16>"  # the 64-column 3x3 conv on 16x16 tiles: largest share of chain time
 PEAK_F16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense f16/bf16 MFMA; the split-precision mode spends 3 f16 MFMA FLOPs per f32 FLOP
 
 

@@ -1013,33 +1013,34 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     }
 }
 
-// Split-precision twin of k_conv_mfma_o (MODE 0 / 1): same tiles, staging, LDS images and addressing; the operands are
-// f16 hi/lo pairs in the H layout and each (chunk, tap) costs 6 x v_mfma_f32_32x32x16_f16 per 32-row sub-tile instead
-// of 16 x v_mfma_f32_32x32x2_f32.  Opt-in ("precision" 1); the f32 kernel stays the default and the parity reference.
+// Split-precision twin of k_conv_mfma_o (MODE 0: 3x3 conv, MODE 1: 2x2 stride-2 transposed conv): same tiles, halo /
+// weight staging, LDS images, swizzles and fragment addressing; the operands are f16 hi/lo pairs in the H layout and each
+// (chunk, tap) costs 6 x v_mfma_f32_32x32x16_f16 per 32-row sub-tile instead of 16 x v_mfma_f32_32x32x2_f32.  No split-K.
+// Opt-in ("precision" 1); the f32 kernel stays the default and the parity reference.
 template <int NT, int MODE, int TH, int OCC, bool FIRST = false>
 __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
     static_assert(MODE == 0 || MODE == 1, "split precision: 3x3 conv and transposed conv only");
     constexpr int TW = 16;
-    constexpr int PAD = (MODE == 0 || MODE == 3) ? 1 : 0;                 // rows/columns of halo above / left of the tile
-    constexpr int HW_ = (MODE == 3) ? TW + 2 : TW + 2 * PAD;             // MODE 3 needs 17 columns; an even pitch keeps
-    constexpr int HH_ = (MODE == 3) ? TH + 1 : TH + 2 * PAD;             // the slot swizzle conflict-free
+    constexpr int PAD = (MODE == 0) ? 1 : 0;
+    constexpr int HW_ = TW + 2 * PAD;
+    constexpr int HH_ = TH + 2 * PAD;
     constexpr int HALO_PIX = HW_ * HH_;
     constexpr int HALO_BYTES = HALO_PIX * 128;
     constexpr int HALO_PIECES = HALO_PIX * 8;
     constexpr int HALO_IT = (HALO_PIECES + 255) / 256;
-    constexpr int TAPS = (MODE == 0) ? 9 : (MODE == 3) ? 4 : 1;
+    constexpr int TAPS = (MODE == 0) ? 9 : 1;
     constexpr int WROWS = 32 * NT;
     constexpr int WBYTES = WROWS * 128;
-    // weight ring: 3 stages for the 3x3 conv, so that a tap's stage (t % 3, nine taps per chunk) is a compile-time
-    // constant and the B-fragment reads need no address arithmetic; 2 stages (runtime parity) elsewhere
-    constexpr int NSTG = (MODE == 0) ? 3 : 2;
+    constexpr int NSTG = (MODE == 0) ? 3 : 2;   // weight ring: a tap's stage is t % 3 (compile time) for the 3x3 conv
+    // Weight slices are staged TWO steps ahead in the 3-stage ring: a step is ~5x shorter than in the f32 kernel (24 MFMAs
+    // of 32 cycles per wave at most), less than the latency of the LDS-DMA that has to land before the next step.
+    constexpr int WAHEAD = (NSTG == 3) ? 2 : 1;
     constexpr int WM = 4 / NT;
     constexpr int MS = (TH / 2) / WM;  // 32-row M sub-tiles (2 pixel rows x 16) per wave
     static_assert(MS >= 1, "tile too small");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const halo0 = smem;
-    unsigned char* const wbuf0 = smem + HALO_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1048,46 +1049,19 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
     const int wm = wave / NT;
     const int li = lane & 31;
     const int lh = lane >> 5;
+    if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(3);   // set-up, DMA issue and epilogue at raised priority (see k_conv_mfma_o)
 
-    // A young wave's VALU/VMEM instructions only get issue slots between the MFMAs of the older waves on its SIMD
-    // (measured: 14 k cycles from entry to the first DMA, 12 k for the epilogue, vs 17 k in the main loop of a
-    // 32-channel layer - tools/ubench/occ_timeline).  Raise the priority outside the main loop so that the address
-    // set-up, the DMA issue and the epilogue are served first; the main loops only need a slot every 64 cycles.
-    if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(3);
-    // diagnostic timeline (tools/ubench/occ_timeline.hip only; nullptr on every product path)
-    unsigned long long* const st = a.stamps ? a.stamps + 8ull * (((unsigned long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) : nullptr;
-    if (st != nullptr && tid == 0) {
-        st[0] = __builtin_amdgcn_s_memtime();
-        st[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID: wave slot, SIMD, CU, SE
-        st[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_REG_XCC_ID
-    }
-
-    // ---- tile decode (scalar).  3-D grid (tile column, tile row, frame x column tile x K part): no integer division
-    //      on the way to the first DMA (each one is ~20 vector-ALU instructions, paid at the contended issue rate).
-    //      split-K (latency mode, MODE 0/1): K part = a range of (chunk, tap) steps ----
-    constexpr int ks_n = 1;   // no split-K in this mode
-    // grid.z = frame group q x (column tile, K part) x frame-in-group: the column tiles of one spatial tile then sit
-    // G * tiles_x * tiles_y (a multiple of 8) blocks apart = on the same XCD, dispatched together, and share the input
-    // tile in that XCD's L2 (G = 2^zgroup_shift frames per group; 1 when tiles_x * tiles_y is already a multiple of 8)
+    // ---- tile decode (scalar): grid = (tile column, tile row, frame group x column tile x frame in group), as k_conv_mfma_o ----
     const int bz = (int)blockIdx.z;
     const int gz = a.zdiv << a.zgroup_shift;
     const int q = (gz == 1) ? bz : (int)(((float)bz + 0.5f) * a.zrcp);   // zrcp = 1 / gz; exact for bz < 2^16
     const int rz = bz - q * gz;
-    const int zr = rz >> a.zgroup_shift;                                   // column tile x K parts + K part
+    const int n_tile = rz >> a.zgroup_shift;
     const int b = (q << a.zgroup_shift) + (rz & ((1 << a.zgroup_shift) - 1));
     if (b >= a.frames) return;   // tail of the last frame group (whole workgroup, before any barrier)
-    const int n_tile = (ks_n == 1) ? zr : zr / ks_n;
-    const int kpart = (ks_n == 1) ? 0 : zr - n_tile * ks_n;
-    constexpr int TAPS_ = (MODE == 0) ? 9 : 1;
-    const int s_lo = (ks_n == 1) ? 0 : (kpart * a.n_chunks * TAPS_) / ks_n;
-    const int s_hi = (ks_n == 1) ? a.n_chunks * TAPS_ : ((kpart + 1) * a.n_chunks * TAPS_) / ks_n;
-    const int c_lo = (ks_n == 1) ? 0 : s_lo / TAPS_;
-    const int c_hi = (ks_n == 1) ? a.n_chunks : (s_hi + TAPS_ - 1) / TAPS_;
     const int ty0 = (int)blockIdx.y * TH;
     const int tx0 = (int)blockIdx.x * TW;
-    // linear ids (split-K partial buffer, diagnostic stamps): as k_splitk_epilogue decodes them
-    const int tile_id = n_tile * a.n_spatial + (b * a.tiles_y + (int)blockIdx.y) * a.tiles_x + (int)blockIdx.x;
-    const int item_id = tile_id * ks_n + kpart;
+    const int n_steps = a.n_chunks * TAPS;
 
     // this frame's input as a raw buffer: offsets past num_records read as zeros (= the conv's zero padding)
     const og_i32x4 in_rsrc = og_make_rsrc(a.in + (long long)b * a.in_frame_stride + a.in_ch_off,
@@ -1098,14 +1072,12 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
     {
         int hy = ((tid >> 3) >= HW_) ? 1 : 0;
         int hx = (tid >> 3) - hy * HW_;
-        const int in_w = (MODE == 3) ? 2 * a.W : a.W;
-        const int row_b = in_w * a.in_pix_stride * ((MODE == 3) ? 8 : 4);   // bytes per halo row step
-        const int col_b = a.in_pix_stride * ((MODE == 3) ? 8 : 4);          // bytes per halo column step
+        const int row_b = a.W * a.in_pix_stride * 4;   // bytes per halo row step
+        const int col_b = a.in_pix_stride * 4;         // bytes per halo column step
 #pragma unroll
         for (int it = 0; it < HALO_IT; ++it) {
             const int logical = (tid & 7) ^ og_halo_swz(hy, hx);
             const int gy = ty0 + hy - PAD, gx = tx0 + hx - PAD;
-            // MODE 3: (gy, gx) is a 2x2 input block = the output pixel grid; the block's (0,0) pixel is the base
             const bool inb = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
             hoff[it] = inb ? (unsigned)(gy * row_b + gx * col_b + logical * 16) : OG_OOB;
             hx += 32 % HW_;
@@ -1116,24 +1088,14 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
     const bool last_valid = ((HALO_IT - 1) * 256 + tid) < HALO_PIECES;
 
     const unsigned lds0 = og_lds_addr(smem);
-    // MODE 3 (3x3 stride-2 conv as a 2x2 stride-1 conv over the space-to-depth view, never materialised):
-    // virtual chunk c = (input-pixel parity par = c / cpc, 32-channel chunk c % cpc)
-    const int cpc = (MODE == 3) ? a.n_chunks >> 2 : 1;
-    auto stage_halo = [&](int buf, int c) {
+    auto stage_halo = [&](int c) {
         const unsigned base = lds0 + wave * 1024;
-        (void)buf;
-        unsigned soff = (unsigned)c * 128u;  // wave-uniform byte offset of the chunk
-        if (MODE == 3) {
-            const int par = c / cpc;
-            soff = (unsigned)((((par >> 1) * 2 * a.W + (par & 1)) * a.in_pix_stride + (c - par * cpc) * 32) * 4);
-        }
 #pragma unroll
         for (int it = 0; it < HALO_IT; ++it) {
-            if (it < HALO_IT - 1 || last_valid) glds16b(hoff[it], in_rsrc, soff, base + it * 4096);
+            if (it < HALO_IT - 1 || last_valid) glds16b(hoff[it], in_rsrc, (unsigned)c * 128u, base + it * 4096);
         }
     };
-    const int total_steps = (MODE == 3) ? cpc * 9 : a.n_chunks * TAPS;  // MODE 3: only the 9 non-zero (tap, parity) pairs
-    const og_i32x4 w_rsrc = og_make_rsrc(a.wpk + (long long)n_tile * total_steps * (WROWS * 32), (unsigned)total_steps * WBYTES);
+    const og_i32x4 w_rsrc = og_make_rsrc(a.wpk + (long long)n_tile * n_steps * (WROWS * 32), (unsigned)n_steps * WBYTES);
     const unsigned woff = (unsigned)tid * 16u;
     auto stage_w = [&](int stage, int step) {
         const unsigned base = lds0 + HALO_BYTES + stage * WBYTES + wave * 1024;
@@ -1142,29 +1104,18 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
     };
 
     // first halo and weights are on their way before the rest of the set-up (which then hides their latency)
-    // Weight slices are staged TWO steps ahead in the 3-stage ring (MODE 0): a step is ~5x shorter than in the f32 kernel
-    // (24 MFMAs of 32 cycles per wave at most), less than the latency of the LDS-DMA that has to land before the next step.
-    constexpr int WAHEAD = (NSTG == 3) ? 2 : 1;
-    const int n_steps_total = (MODE == 3) ? total_steps : a.n_chunks * TAPS;
     if (!FIRST) {
-        if (st != nullptr && tid == 0) st[6] = __builtin_amdgcn_s_memtime();
-        stage_halo(0, c_lo);
-        stage_w((NSTG == 3) ? s_lo % 3 : (s_lo & 1), s_lo);
-        if (WAHEAD == 2 && s_lo + 1 < n_steps_total) stage_w((s_lo + 1) % 3, s_lo + 1);
+        stage_halo(0);
+        stage_w(0, 0);
+        if (WAHEAD == 2 && 1 < n_steps) stage_w(1, 1);
     }
 
-    // ---- fragment addressing ----
-    // A rows: i -> 2x2-window-major pixel order, so that the 4 accumulator registers
-    // (reg&3) of one lane are exactly one pooling window (see epilogue).
+    // ---- fragment addressing: exactly k_conv_mfma_o's (2x2-window-major pixel order, 12 A registers, 4 B registers) ----
     const int px0 = 2 * (li >> 2) + (li & 1);
     const int pyl = (li >> 1) & 1;
     const int brow = wn * 32 + li;
     const int boff = brow * 128 + ((lh ^ ((brow >> 1) & 7)) << 4);
-    // Everything lane-dependent of an A-fragment address sits in NDX x 4 registers:
-    //   abase[dx][pat] = ((pyl*HW_ + px0+dx) * 128 + ((lh ^ swz(pyl, px0+dx)) << 4) + wave row offset) ^ (pat << 5)
-    // and a tap's dy, the k-group j and the M sub-tile m only select pat = j ^ ((dy & 1) << 1) (row parity flips slot
-    // bit 2) and add the compile-time constant (dy + 2m) * HW_ * 128, which the ds_read carries as its immediate.
-    constexpr int NDX = (MODE == 0) ? 3 : (MODE == 3) ? 2 : 1;
+    constexpr int NDX = (MODE == 0) ? 3 : 1;
     unsigned abase[NDX][4];
 #pragma unroll
     for (int dx = 0; dx < NDX; ++dx) {
@@ -1176,7 +1127,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
             asm volatile("" : "+v"(abase[dx][pat]));              // opaque: or hipcc re-adds the (link-time 0) smem base per read
         }
     }
-    unsigned bbase[4];   // B fragments: stage 0 of the weight ring, k-group j
+    unsigned bbase[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         bbase[jj] = lds0 + HALO_BYTES + (unsigned)(boff ^ (jj << 5));
@@ -1198,8 +1149,8 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
         }
 
     if (FIRST) {
-        // halo tile of the first layer's OUTPUT, computed here: 12x20 u8 patch -> /255 -> 3x3 conv -> BN -> ReLU,
-        // written in the same swizzled [pixel][8 x 16 B] image the LDS-DMA would have produced
+        // halo tile of the first layer's OUTPUT, computed here: 12x20 u8 patch -> /255 -> 3x3 conv -> BN -> ReLU, split and
+        // written in the swizzled H-layout image the LDS-DMA would have produced
         float* patch = (float*)(smem + HALO_BYTES + NSTG * WBYTES);  // [HH_+2][HW_+2]
         float* fw = patch + (HH_ + 2) * (HW_ + 2);                // w9[9][32] | scale[32] | shift[32]
         const uint8_t* fin = a.first_u8 + (long long)b * a.H * a.W;
@@ -1210,11 +1161,11 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
         }
         for (int i = tid; i < 352; i += 256) fw[i] = (i < 288) ? a.first_w9[i] : (i < 320 ? a.first_scale[i - 288] : a.first_shift[i - 320]);
         stage_w(0, 0);
-        if (WAHEAD == 2 && 1 < n_steps_total) stage_w(1, 1);
+        if (WAHEAD == 2 && 1 < n_steps) stage_w(1, 1);
         __syncthreads();
         // one item = (halo pixel, 8-channel group L): the fma chain of k_conv_first for 8 channels, then hi -> slot L, lo -> slot 4+L
-        for (int q = tid; q < HALO_PIX * 4; q += 256) {
-            const int p = q >> 2, L = q & 3;
+        for (int q2 = tid; q2 < HALO_PIX * 4; q2 += 256) {
+            const int p = q2 >> 2, L = q2 & 3;
             const int hy = p / HW_, hx = p - hy * HW_;
             const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
             _Float16 hi[8], lo[8];
@@ -1246,29 +1197,21 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
         }
     }
     og_wait_dma();
-    if (st != nullptr && tid == 0) st[7] = __builtin_amdgcn_s_memtime();
     __syncthreads();
-    if (st != nullptr && tid == 0) st[1] = __builtin_amdgcn_s_memtime();
     if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(0);
 
-    int step = s_lo;                             // absolute (chunk, tap) index: also the weight block's index
-    const int step_end = (MODE == 3) ? total_steps : s_hi;
-    for (int c = c_lo; c < c_hi; ++c) {
+    int step = 0;   // (chunk, tap) index: also the weight block's index
+    for (int c = 0; c < a.n_chunks; ++c) {
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
-            if ((MODE == 0 || MODE == 1) && ks_n > 1 && (c * TAPS + t < s_lo || c * TAPS + t >= s_hi)) continue;  // another K part's step
-            if (MODE == 3) {  // tap (ty,tx) of the 2x2 kernel meets parity (py,px): zero unless (ty==1 || py==1) and (tx==1 || px==1)
-                const int par = c / cpc;
-                if (((t >> 1) == 0 && (par & 2) == 0) || ((t & 1) == 0 && (par & 1) == 0)) continue;
-            }
             const int stg = (NSTG == 3) ? t % 3 : (step & 1), stg_next = (NSTG == 3) ? (t + WAHEAD) % 3 : ((step + 1) & 1);
-            const bool more = (step + WAHEAD < step_end);
+            const bool more = (step + WAHEAD < n_steps);
             if (more) stage_w(stg_next, step + WAHEAD);
 
             const unsigned wb = (unsigned)stg * WBYTES;
-            const int dy = (MODE == 0) ? t / 3 : (MODE == 3) ? (t >> 1) : 0;
-            const int dx = (MODE == 0) ? t % 3 : (MODE == 3) ? (t & 1) : 0;
-            // k-group j -> 16-byte slot 2j + lh of the 128-byte row: j = 0,1 the hi halves of k-steps 0,1 (channels 16t + 8lh ..),
+            const int dy = (MODE == 0) ? t / 3 : 0;
+            const int dx = (MODE == 0) ? t % 3 : 0;
+            // k-group j -> 16-byte slot 2j + lh of the 128-byte row: j = 0,1 the hi halves of k-steps 0,1 (channels 16j + 8lh ..),
             // j = 2,3 their lo halves -- the same four reads per fragment as the f32 kernel, other contents
             f32x4 bv[4];
 #pragma unroll
@@ -1291,32 +1234,24 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
             __syncthreads();
             ++step;
         }
-        if (c + 1 < c_hi) {  // every read of the halo buffer completed before the barrier above
-            stage_halo(0, c + 1);
+        if (c + 1 < a.n_chunks) {  // every read of the halo buffer completed before the barrier above
+            stage_halo(c + 1);
             og_wait_dma();
             __syncthreads();
         }
     }
 
-    if (st != nullptr && tid == 0) st[2] = __builtin_amdgcn_s_memtime();
     if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(3);
     // ---- epilogue (all staging buffers are dead behind the last barrier: LDS is scratch now) ----
 #pragma unroll
     for (int m = 0; m < MS; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = fmaf(cor[m][r], OG_LO_INV, acc[m][r]);
-    {
-        unsigned char* const scr = smem + wave * 5120;
-        // activations leave in the H layout; the launch with the fused head stores no activation and keeps the f32 scratch
-        if (a.act == 1) conv_epilogue_b<NT, MODE, TH, 1, false, true>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
-        else conv_epilogue_b<NT, MODE, TH, 0, false, true>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
-    }
-    if (st != nullptr && tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        st[3] = __builtin_amdgcn_s_memtime();
-    }
+    unsigned char* const scr = smem + wave * 5120;
+    // activations leave in the H layout; the launch with the fused head stores no activation and keeps the f32 scratch
+    if (a.act == 1) conv_epilogue_b<NT, MODE, TH, 1, false, true>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+    else conv_epilogue_b<NT, MODE, TH, 0, false, true>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
 }
-
 
 // ---------------------------------------------------------------------------------------
 // Generation 2 of the implicit-GEMM conv: PERSISTENT workgroups walking a flat sequence of
