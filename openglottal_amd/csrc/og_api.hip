@@ -169,6 +169,7 @@ struct og_unet {
     } ring;
     int precision = 0;     // 0: exact f32 (v_mfma_f32_32x32x2_f32) -- the default and the parity reference; 1: opt-in split precision
                            // (f16 hi/lo pairs, 3 x v_mfma_f32_32x32x16_f16 per f32 product, f32 accumulation; k_conv_mfma_h)
+    int h_square = 1;      // split precision, 64-column kernel on 16x16 tiles: 2x2 sub-tiles per wave (fewer LDS reads per MFMA)
     int stream_host = 1;   // og_unet_segment_u8 goes through the streaming engine (0: one-shot staging of the whole batch)
 };
 
@@ -489,7 +490,7 @@ int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     return OG_OK;
 }
 
-template <int NT, int MODE, int TH, int OCC>
+template <int NT, int MODE, int TH, int OCC, bool SQ = false>
 int launch_conv_h(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {   // split-precision twin of launch_conv_o (no split-K)
     constexpr int lds = conv_o_lds<NT, MODE, TH>();
     ConvArgs a = a_in;
@@ -509,7 +510,7 @@ int launch_conv_h(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {   //
     const int G = 1 << a.zgroup_shift, groups = (frames + G - 1) / G;
     a.zrcp = 1.0f / (float)(a.zdiv * G);
     if ((long long)groups * G * a.zdiv > 65535) return fail(OG_EINVAL, "micro-batch too large for one launch (grid.z): lower the chunk size");
-    hipLaunchKernelGGL((k_conv_mfma_h<NT, MODE, TH, OCC>), dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), lds, c.stream, a);
+    hipLaunchKernelGGL((k_conv_mfma_h<NT, MODE, TH, OCC, false, SQ>), dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), lds, c.stream, a);
     HIPCHK(hipGetLastError());
     return OG_OK;
 }
@@ -572,6 +573,7 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<1, 0, 8, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                conv_o_lds<1, 0, 8>() + (12 * 20 + 352) * 4));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<2, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 16>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<2, 0, 16, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 16>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<1, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 16>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<2, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_h<1, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 8>()));
@@ -670,7 +672,8 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
             const double fl = 2.0 * px_h * 9.0 * L.Cin * L.Cout;
             if (big) {
                 prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma_h<2,0,16>" : "k_conv_mfma_h<1,0,16>", fl);
-                rc_h = (L.NT == 2) ? launch_conv_h<2, 0, 16, 2>(ctx, a, n_ntiles) : launch_conv_h<1, 0, 16, 2>(ctx, a, n_ntiles);
+                if (L.NT == 2) rc_h = h->h_square ? launch_conv_h<2, 0, 16, 2, true>(ctx, a, n_ntiles) : launch_conv_h<2, 0, 16, 2>(ctx, a, n_ntiles);
+                else rc_h = launch_conv_h<1, 0, 16, 2>(ctx, a, n_ntiles);
             } else {
                 prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma_h<2,0,8>" : "k_conv_mfma_h<1,0,8>", fl);
                 rc_h = (L.NT == 2) ? launch_conv_h<2, 0, 8, 3>(ctx, a, n_ntiles) : launch_conv_h<1, 0, 8, 3>(ctx, a, n_ntiles);
@@ -1434,6 +1437,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "lanes" && value >= 0 && value <= kMaxLanes) slot = &h->n_lanes;
     else if (n == "stream" && (value == 0 || value == 1)) slot = &h->stream_host;
     else if (n == "precision" && (value == 0 || value == 1)) slot = &h->precision;
+    else if (n == "h_square" && (value == 0 || value == 1)) slot = &h->h_square;
     if (!slot) return fail(OG_EINVAL, "unknown option or bad value: " + n);
     if (*slot != value) {
         if (h->stream) HIPCHK(hipStreamSynchronize(h->stream));

@@ -507,12 +507,12 @@ __device__ __forceinline__ void og_buffer_store16(f32x4 v, __amdgpu_buffer_rsrc_
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(og_u32x4, v), rs, voff, soff, 0);
 #endif
 }
-template <int NT, int MODE, int TH, int ACT, bool RES, bool HALF = false>
+template <int NT, int MODE, int TH, int ACT, bool RES, bool HALF = false, int MSO = 0>
 __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16* acc, int n_tile, int b, int ty0, int tx0, int wm, int wn,
                                                 int li, int lh, float sc, float sh, unsigned char* scratch) {
     constexpr int WROWS = 32 * NT;
     constexpr int WM = 4 / NT;
-    constexpr int MS = (TH / 2) / WM;
+    constexpr int MS = MSO ? MSO : (TH / 2) / WM;   // MSO: sub-tiles per wave when the caller lays its waves out differently (wm then counts in units of MSO)
     const int lane = li + 32 * lh;
     const int ncol0 = n_tile * WROWS + wn * 32;
     int cbase = ncol0, qd = 0;
@@ -1017,9 +1017,12 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
 // weight staging, LDS images, swizzles and fragment addressing; the operands are f16 hi/lo pairs in the H layout and each
 // (chunk, tap) costs 6 x v_mfma_f32_32x32x16_f16 per 32-row sub-tile instead of 16 x v_mfma_f32_32x32x2_f32.  No split-K.
 // Opt-in ("precision" 1); the f32 kernel stays the default and the parity reference.
-template <int NT, int MODE, int TH, int OCC, bool FIRST = false>
+// SQ (NT == 2, TH == 16 only): every wave computes 2 row sub-tiles x BOTH 32-column sub-tiles instead of 4 x 1 -- 16 instead
+// of 20 fragment reads per 24 MFMAs; LDS reads are what this kernel's MFMA rate is paid with (tools/ubench/mfma_f16_split).
+template <int NT, int MODE, int TH, int OCC, bool FIRST = false, bool SQ = false>
 __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
     static_assert(MODE == 0 || MODE == 1, "split precision: 3x3 conv and transposed conv only");
+    static_assert(!SQ || (NT == 2 && TH == 16 && !FIRST), "square wave tiles: 64-column kernel on 16x16 tiles");
     constexpr int TW = 16;
     constexpr int PAD = (MODE == 0) ? 1 : 0;
     constexpr int HW_ = TW + 2 * PAD;
@@ -1035,8 +1038,9 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
     // Weight slices are staged TWO steps ahead in the 3-stage ring: a step is ~5x shorter than in the f32 kernel (24 MFMAs
     // of 32 cycles per wave at most), less than the latency of the LDS-DMA that has to land before the next step.
     constexpr int WAHEAD = (NSTG == 3) ? 2 : 1;
-    constexpr int WM = 4 / NT;
-    constexpr int MS = (TH / 2) / WM;  // 32-row M sub-tiles (2 pixel rows x 16) per wave
+    constexpr int WM = SQ ? 4 : 4 / NT;          // waves along M
+    constexpr int NC = SQ ? 2 : 1;               // 32-column sub-tiles per wave
+    constexpr int MS = (TH / 2) / WM;            // 32-row M sub-tiles (2 pixel rows x 16) per wave
     static_assert(MS >= 1, "tile too small");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1045,8 +1049,8 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave % NT;
-    const int wm = wave / NT;
+    const int wn = SQ ? 0 : wave % NT;
+    const int wm = SQ ? wave : wave / NT;
     const int li = lane & 31;
     const int lh = lane >> 5;
     if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(3);   // set-up, DMA issue and epilogue at raised priority (see k_conv_mfma_o)
@@ -1135,18 +1139,25 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
     }
 
     // this lane's output channel: folded BN scale / shift, loaded now so that the epilogue does not wait for them
-    const int ecol = n_tile * WROWS + wn * 32 + li;
-    const int eco = (MODE == 1) ? ecol % a.aff_mod : ecol;
-    const float esc = a.scale[eco], esh = a.shift[eco];
+    float esc[NC], esh[NC];
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+        const int ecol = n_tile * WROWS + (wn + n) * 32 + li;
+        const int eco = (MODE == 1) ? ecol % a.aff_mod : ecol;
+        esc[n] = a.scale[eco];
+        esh[n] = a.shift[eco];
+    }
 
-    f32x16 acc[MS], cor[MS];   // hi*hi | hi*lo + lo*hi (scaled by 2^11)
+    f32x16 acc[NC][MS], cor[NC][MS];   // hi*hi | hi*lo + lo*hi (scaled by 2^11)
 #pragma unroll
-    for (int m = 0; m < MS; ++m)
+    for (int n = 0; n < NC; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            acc[m][r] = 0.f;
-            cor[m][r] = 0.f;
-        }
+        for (int m = 0; m < MS; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[n][m][r] = 0.f;
+                cor[n][m][r] = 0.f;
+            }
 
     if (FIRST) {
         // halo tile of the first layer's OUTPUT, computed here: 12x20 u8 patch -> /255 -> 3x3 conv -> BN -> ReLU, split and
@@ -1213,20 +1224,24 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
             const int dx = (MODE == 0) ? t % 3 : 0;
             // k-group j -> 16-byte slot 2j + lh of the 128-byte row: j = 0,1 the hi halves of k-steps 0,1 (channels 16j + 8lh ..),
             // j = 2,3 their lo halves -- the same four reads per fragment as the f32 kernel, other contents
-            f32x4 bv[4];
+            f32x4 bv[NC][4];   // column sub-tile n: rows 32n.. of the weight slice = +4096 bytes (same swizzle: (32n + li) >> 1 & 7 = li >> 1 & 7)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = og_lds_read16(bbase[j] + wb);
+            for (int n = 0; n < NC; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[n][j] = og_lds_read16(bbase[j] + wb + (unsigned)(n * 4096));
 #pragma unroll
             for (int m = 0; m < MS; ++m) {
                 f32x4 av[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) av[j] = og_lds_read16(abase[dx][j ^ ((dy & 1) << 1)] + (unsigned)((dy + 2 * m) * (HW_ * 128)));
 #pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2) {
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(og_h8, av[t2]), __builtin_bit_cast(og_h8, bv[t2]), acc[m], 0, 0, 0);
-                    cor[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(og_h8, av[t2]), __builtin_bit_cast(og_h8, bv[2 + t2]), cor[m], 0, 0, 0);
-                    cor[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(og_h8, av[2 + t2]), __builtin_bit_cast(og_h8, bv[t2]), cor[m], 0, 0, 0);
-                }
+                for (int n = 0; n < NC; ++n)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(og_h8, av[t2]), __builtin_bit_cast(og_h8, bv[n][t2]), acc[n][m], 0, 0, 0);
+                        cor[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(og_h8, av[t2]), __builtin_bit_cast(og_h8, bv[n][2 + t2]), cor[n][m], 0, 0, 0);
+                        cor[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(og_h8, av[2 + t2]), __builtin_bit_cast(og_h8, bv[n][t2]), cor[n][m], 0, 0, 0);
+                    }
             }
             // the NEXT step's slice must have landed; the one staged just now (NT instructions per wave) may stay in flight
             if (WAHEAD == 2 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT) : "memory");
@@ -1243,14 +1258,17 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
 
     if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(3);
     // ---- epilogue (all staging buffers are dead behind the last barrier: LDS is scratch now) ----
-#pragma unroll
-    for (int m = 0; m < MS; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = fmaf(cor[m][r], OG_LO_INV, acc[m][r]);
     unsigned char* const scr = smem + wave * 5120;
-    // activations leave in the H layout; the launch with the fused head stores no activation and keeps the f32 scratch
-    if (a.act == 1) conv_epilogue_b<NT, MODE, TH, 1, false, true>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
-    else conv_epilogue_b<NT, MODE, TH, 0, false, true>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+#pragma unroll
+        for (int m = 0; m < MS; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][m][r] = fmaf(cor[n][m][r], OG_LO_INV, acc[n][m][r]);
+        // activations leave in the H layout; the launch with the fused head stores no activation and keeps the f32 scratch
+        if (a.act == 1) conv_epilogue_b<NT, MODE, TH, 1, false, true, MS>(a, acc[n], n_tile, b, ty0, tx0, wm, wn + n, li, lh, esc[n], esh[n], scr);
+        else conv_epilogue_b<NT, MODE, TH, 0, false, true, MS>(a, acc[n], n_tile, b, ty0, tx0, wm, wn + n, li, lh, esc[n], esh[n], scr);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
