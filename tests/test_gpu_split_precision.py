@@ -122,3 +122,68 @@ def test_odd_shapes_and_padded_channels_split_precision():
         assert np.abs(logits[:4] - ref_logits).max() <= TOL * scale, (feats, np.abs(logits[:4] - ref_logits).max())
         assert np.all(np.abs(ref_logits[(masks[:4] > 0) != (ref_mask > 0)]) <= TOL * scale)
         assert np.array_equal(areas, (masks > 0).reshape(B, -1).sum(1))
+
+
+def test_randomised_entry_point_matrix_both_precisions():
+    """Randomised sweep over the entry points and knobs a caller can combine -- frame size, batch, micro-batch, lanes,
+    graphs, boxes, mask / logits requests, host vs streamed vs device pointers, both precisions -- on a small net, each
+    configuration against the CPU oracle (logits within tolerance, masks by the flip rule, areas = popcount [in box])."""
+    import torch
+
+    from oracle import unet_oracle as O
+    from openglottal_amd.utils import normalize_box
+
+    rs = np.random.RandomState(2026)
+    feats = (8, 16, 32)
+    sd = synth.make_unet_state_dict(feats, seed=77, head_scale=2.5, head_bias=-0.2)
+    m = make_model(sd, feats, precision=0)
+    dev = torch.device("cuda", 0)
+    cache = {}
+    for it in range(60):
+        H, W = [(32, 48), (64, 64), (40, 72), (8, 16), (96, 32)][rs.randint(5)]
+        B = int(rs.choice([1, 2, 3, 5, 17, 40]))
+        key = (H, W, B)
+        if key not in cache:
+            fr = rs.randint(0, 256, (B, H, W), dtype=np.uint8)
+            cache[key] = (fr,) + O.segment_frames(sd, fr, backend="torch")
+        fr, ref_mask, ref_logits = cache[key]
+        prec = int(rs.randint(2))
+        m.set_option("precision", prec)
+        m.set_chunk(int(rs.choice([1, 2, 4, 16, 64])))
+        m.set_option("lanes", int(rs.randint(4)))
+        m.set_graphs(bool(rs.randint(2)))
+        m.set_option("stream", int(rs.randint(2)))
+        boxes = None
+        if rs.randint(2):
+            boxes = np.array([normalize_box((int(rs.randint(-5, W)), int(rs.randint(-5, H)), int(rs.randint(0, W + 9)), int(rs.randint(0, H + 9))), W, H)
+                              for _ in range(B)], np.int32)
+            boxes[rs.randint(B)] = -1
+        how = int(rs.randint(3))
+        if how == 0:
+            masks, areas, logits = m.segment(fr, boxes=boxes, want_logits=True)
+        elif how == 1:
+            masks, areas = m.segment_stream(fr, boxes=boxes, want_mask=True)
+            logits = None
+        else:
+            d_f = torch.from_numpy(fr).to(dev)
+            d_a = torch.zeros(B, dtype=torch.int32, device=dev)
+            d_m = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
+            d_l = torch.zeros((B, H, W), dtype=torch.float32, device=dev)
+            m.segment_dev(d_f, B, H, W, d_a, boxes_dev=None if boxes is None else torch.from_numpy(boxes).to(dev), mask_dev=d_m, logits_dev=d_l)
+            m.sync()
+            masks, areas, logits = d_m.cpu().numpy(), d_a.cpu().numpy(), d_l.cpu().numpy()
+        cfg = (it, H, W, B, prec, how)
+        scale = max(1.0, np.abs(ref_logits).max())
+        if logits is not None:
+            assert np.abs(logits - ref_logits).max() <= TOL * scale, cfg
+        diff = (masks > 0) != (ref_mask > 0)
+        assert np.all(np.abs(ref_logits[diff]) <= TOL * scale), cfg
+        for i in range(B):
+            if boxes is None:
+                want = int((masks[i] > 0).sum())
+            elif boxes[i][0] < 0:
+                want = 0
+            else:
+                x1, y1, x2, y2 = boxes[i]
+                want = int((masks[i][y1:y2, x1:x2] > 0).sum())
+            assert int(areas[i]) == want, cfg + (i,)
