@@ -134,20 +134,17 @@ def sharded_gated_area_waveform(frames_bgr, detect_batch, make_detector, model, 
     return all_gather_areas(ta, n, group).cpu().numpy(), boxes
 
 
-def sharded_eval_counts(n_frames: int, count_fn, rank: int, world: int, device=None, group=None) -> np.ndarray:
+def sharded_eval_counts(n_frames: int, count_fn, rank: int, world: int, device=None, group=None, width: int = 10) -> np.ndarray:
     """BASELINE config C5 (BAGLS evaluation sharded over the GPUs of a node): the detector is reset before every frame
     (scripts/eval_bagls.py:164-166), so frames are fully independent — each rank evaluates ITS contiguous shard
     (``count_fn(lo, hi) -> int [hi-lo, width]``, e.g. ``evaluate.evaluate_counts_device`` on ``frames[lo:hi]``) and ONE
     all-gather of the per-frame integer count rows gives every rank the whole table (40 bytes per frame; the masks never
-    leave their GPU).  Counts stay below 2^24, so the float32 rows of ``all_gather_rows`` carry them exactly."""
+    leave their GPU).  Counts stay below 2^24, so the float32 rows of ``all_gather_rows`` carry them exactly.  ``width`` is
+    stated by the caller (not inferred) so that a rank with an empty shard posts a collective of the same shape."""
     import torch
 
     lo, hi = shard_range(n_frames, rank, world)
-    local = np.asarray(count_fn(lo, hi)) if hi > lo else None
-    width = local.shape[1] if local is not None else None
-    if width is None:   # an empty shard still has to know the row width: agree on it through the collective's shape below
-        width = 10
-        local = np.zeros((0, width), np.int64)
+    local = np.asarray(count_fn(lo, hi)).reshape(-1, width) if hi > lo else np.zeros((0, width), np.int64)
     assert int(local.max(initial=0)) < (1 << 24)
     t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32))
     if device is not None:
