@@ -495,10 +495,9 @@ int launch_conv_h(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {   //
     constexpr int lds = conv_o_lds<NT, MODE, TH>();
     ConvArgs a = a_in;
     a.stamps = nullptr;
-    a.ksplit = 1;
-    a.tile_counter = nullptr;
+    if (SQ || a.tile_counter == nullptr || a.partial == nullptr || a.n_spatial * n_ntiles > 4096) a.ksplit = 1;   // fused reduce only
     const int frames = a.n_spatial / (a.tiles_x * a.tiles_y);
-    a.zdiv = n_ntiles;
+    a.zdiv = n_ntiles * a.ksplit;
     a.frames = frames;
     a.zgroup_shift = 0;
     if (c.xcd_group && a.zdiv > 1) {
@@ -659,6 +658,15 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         // more: 16-row tiles wherever they tile the image ("tile_h" 8 forces 8 rows, 16 / 0 = this rule)
         big = full16 && h->tile_h != 8;
         if (a.head_w != nullptr) big = false;   // per-tile count slots of the fused head are laid out for 8x16 tiles
+        {   // small launches (one frame per chain): split K over workgroups exactly as the f32 occupancy kernel does
+            const int nt_s = (L.mode == 0) ? L.Cout_p / (32 * L.NT) : 4 * L.Cout_p / 64;
+            const int tiles8 = B * a.tiles_x * ((in.H + 7) / 8);
+            const int k_units = (L.mode == 0) ? (a.n_chunks * 9) / h->splitk_min_steps : a.n_chunks;
+            const int ks = pick_ksplit(tiles8 * nt_s, k_units, h->n_cu * h->splitk_slots, (L.NT == 2) ? 2 : 1,
+                                       h->splitk != 0 && h->d_partial != nullptr && h->d_tile_counter != nullptr, h->splitk_div);
+            a.ksplit = (ks > 1 && a.head_w == nullptr) ? ks : 1;
+            if (a.ksplit > 1) big = false;
+        }
         const int th_h = big ? 16 : 8;
         a.tiles_y = (in.H + th_h - 1) / th_h;
         a.n_spatial = B * a.tiles_x * a.tiles_y;

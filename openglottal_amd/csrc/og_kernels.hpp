@@ -1060,12 +1060,21 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
     const int gz = a.zdiv << a.zgroup_shift;
     const int q = (gz == 1) ? bz : (int)(((float)bz + 0.5f) * a.zrcp);   // zrcp = 1 / gz; exact for bz < 2^16
     const int rz = bz - q * gz;
-    const int n_tile = rz >> a.zgroup_shift;
+    const int zr = rz >> a.zgroup_shift;                                   // column tile x K parts + K part
     const int b = (q << a.zgroup_shift) + (rz & ((1 << a.zgroup_shift) - 1));
     if (b >= a.frames) return;   // tail of the last frame group (whole workgroup, before any barrier)
+    // split-K (small launches, one frame per chain): K part = a range [s_lo, s_hi) of (chunk, tap) steps; the last part of a
+    // tile to arrive sums all parts in split order and runs the epilogue (as k_conv_mfma_o; not with the square wave tiles)
+    const int ks_n = SQ ? 1 : a.ksplit;
+    const int n_tile = (ks_n == 1) ? zr : zr / ks_n;
+    const int kpart = (ks_n == 1) ? 0 : zr - n_tile * ks_n;
     const int ty0 = (int)blockIdx.y * TH;
     const int tx0 = (int)blockIdx.x * TW;
     const int n_steps = a.n_chunks * TAPS;
+    const int s_lo = (ks_n == 1) ? 0 : (kpart * n_steps) / ks_n;
+    const int s_hi = (ks_n == 1) ? n_steps : ((kpart + 1) * n_steps) / ks_n;
+    const int c_lo = s_lo / TAPS, c_hi = (s_hi + TAPS - 1) / TAPS;
+    const int tile_id = n_tile * a.n_spatial + (b * a.tiles_y + (int)blockIdx.y) * a.tiles_x + (int)blockIdx.x;
 
     // this frame's input as a raw buffer: offsets past num_records read as zeros (= the conv's zero padding)
     const og_i32x4 in_rsrc = og_make_rsrc(a.in + (long long)b * a.in_frame_stride + a.in_ch_off,
@@ -1109,9 +1118,9 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
 
     // first halo and weights are on their way before the rest of the set-up (which then hides their latency)
     if (!FIRST) {
-        stage_halo(0);
-        stage_w(0, 0);
-        if (WAHEAD == 2 && 1 < n_steps) stage_w(1, 1);
+        stage_halo(c_lo);
+        stage_w((NSTG == 3) ? s_lo % 3 : (s_lo & 1), s_lo);
+        if (WAHEAD == 2 && s_lo + 1 < s_hi) stage_w((s_lo + 1) % 3, s_lo + 1);
     }
 
     // ---- fragment addressing: exactly k_conv_mfma_o's (2x2-window-major pixel order, 12 A registers, 4 B registers) ----
@@ -1211,12 +1220,13 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
     __syncthreads();
     if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(0);
 
-    int step = 0;   // (chunk, tap) index: also the weight block's index
-    for (int c = 0; c < a.n_chunks; ++c) {
+    int step = s_lo;   // absolute (chunk, tap) index: also the weight block's index (stage = step % 3 = t % 3: 9 taps per chunk)
+    for (int c = c_lo; c < c_hi; ++c) {
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
+            if (ks_n > 1 && (c * TAPS + t < s_lo || c * TAPS + t >= s_hi)) continue;  // another K part's step
             const int stg = (NSTG == 3) ? t % 3 : (step & 1), stg_next = (NSTG == 3) ? (t + WAHEAD) % 3 : ((step + 1) & 1);
-            const bool more = (step + WAHEAD < n_steps);
+            const bool more = (step + WAHEAD < s_hi);
             if (more) stage_w(stg_next, step + WAHEAD);
 
             const unsigned wb = (unsigned)stg * WBYTES;
@@ -1249,7 +1259,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
             __syncthreads();
             ++step;
         }
-        if (c + 1 < a.n_chunks) {  // every read of the halo buffer completed before the barrier above
+        if (c + 1 < c_hi) {  // every read of the halo buffer completed before the barrier above
             stage_halo(c + 1);
             og_wait_dma();
             __syncthreads();
@@ -1260,11 +1270,40 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
     // ---- epilogue (all staging buffers are dead behind the last barrier: LDS is scratch now) ----
     unsigned char* const scr = smem + wave * 5120;
 #pragma unroll
-    for (int n = 0; n < NC; ++n) {
+    for (int n = 0; n < NC; ++n)
 #pragma unroll
         for (int m = 0; m < MS; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][m][r] = fmaf(cor[n][m][r], OG_LO_INV, acc[n][m][r]);
+    if (!SQ && ks_n > 1) {
+        // this part's (combined, f32) accumulators: device-scope write-through stores, then the arrival counter
+        float* pw = a.partial + (((long long)tile_id * ks_n + kpart) * 4 + wave) * (MS * 16 * 64) + lane;
+#pragma unroll
+        for (int m = 0; m < MS; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __hip_atomic_store(pw + (m * 16 + r) * 64, acc[0][m][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part is written through
+        __syncthreads();
+        int* const flag = (int*)smem;
+        if (tid == 0) *flag = (atomicAdd(a.tile_counter + tile_id, 1) == ks_n - 1) ? 1 : 0;
+        __syncthreads();
+        if (!*(volatile int*)flag) return;   // not the last part of this tile
+#pragma unroll
+        for (int m = 0; m < MS; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][m][r] = 0.f;
+        for (int sp_ = 0; sp_ < ks_n; ++sp_) {   // every part from memory, in split order: the sum does not depend on who is last
+            const float* pr = a.partial + (((long long)tile_id * ks_n + sp_) * 4 + wave) * (MS * 16 * 64) + lane;
+#pragma unroll
+            for (int m = 0; m < MS; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][m][r] += __hip_atomic_load(pr + (m * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();   // the flag word is part of wave 0's scratch
+        if (tid == 0) a.tile_counter[tile_id] = 0;   // ready for the next launch on this stream
+    }
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
         // activations leave in the H layout; the launch with the fused head stores no activation and keeps the f32 scratch
         if (a.act == 1) conv_epilogue_b<NT, MODE, TH, 1, false, true, MS>(a, acc[n], n_tile, b, ty0, tx0, wm, wn + n, li, lh, esc[n], esh[n], scr);
         else conv_epilogue_b<NT, MODE, TH, 0, false, true, MS>(a, acc[n], n_tile, b, ty0, tx0, wm, wn + n, li, lh, esc[n], esh[n], scr);
