@@ -329,14 +329,17 @@ def main() -> None:
         rl, per = roofline("k_conv_mfma_h", round(PEAK_F16_MFMA_TFLOPS / 3, 1),
                            "achieved = algorithmic f32-equivalent FLOP/s; peak = dense f16 MFMA peak / 3 (three f16 MFMAs per f32 product); "
                            "the bare 3-MFMA loop on random data sustains 454-526 of it (tools/ubench/mfma_f16_split)")
-        n1 = min(F, 256)
-        model.set_chunk(1)
-        model.segment_dev(frames, n1, 256, 256, area); model.sync()
-        fence(); t1 = time.perf_counter()
-        model.segment_dev(frames, n1, 256, 256, area); model.sync()
-        fence(); e1 = time.perf_counter() - t1
-        model.set_chunk(args.chunk)
-        out["split_precision"] = {"value": round(fps2, 1), "latency_mode": {"frames_per_launch": 1, "value": round(n1 / e1, 1), "unit": "frames/s", "frames": n1}, "unit": "frames/s", "vs_f32_path": round(fps2 / fps, 3), "dtype": "f16 hi/lo x3 MFMA, f32 accumulate",
+        lat2 = None
+        if not args.no_latency_mode:
+            n1 = min(F, 256)
+            model.set_chunk(1)
+            model.segment_dev(frames, n1, 256, 256, area); model.sync()
+            fence(); t1 = time.perf_counter()
+            model.segment_dev(frames, n1, 256, 256, area); model.sync()
+            fence(); e1 = time.perf_counter() - t1
+            model.set_chunk(args.chunk)
+            lat2 = {"frames_per_launch": 1, "value": round(n1 / e1, 1), "unit": "frames/s", "frames": n1}
+        out["split_precision"] = {"value": round(fps2, 1), "latency_mode": lat2, "unit": "frames/s", "vs_f32_path": round(fps2 / fps, 3), "dtype": "f16 hi/lo x3 MFMA, f32 accumulate",
                                   "ms_per_step": round(1e3 * e2 / args.steps, 3), "tflops_f32_equivalent": round(fps2 * model.flops_per_frame(256, 256) / 1e12, 2),
                                   "frames_whose_area_differs_from_f32_path": flips,
                                   "chain_frac_hbm_layer_boundary_model": round(fps2 * LAYER_BOUNDARY_BYTES_PER_FRAME / PEAK_HBM_BYTES, 4),
