@@ -20,6 +20,7 @@ S = 256
 feats = (32, 64, 128, 256)
 m = og.UNet(1, 1, feats); m.load_state_dict(synth.make_unet_state_dict(feats, seed=5, head_scale=3.0, head_bias=-2.5)); m.to("cuda:0").eval()
 m.set_chunk(64)
+m.set_option("precision", int(os.environ.get("OG_PRECISION", "0")))   # 1: the opt-in split-precision kernels
 y = YoloV8Detector(synth.make_yolov8_state_dict(seed=7), device="cuda:0")
 bgr = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (F, S, S, 3), dtype=np.uint8)).cuda()
 gray = torch.empty((F, S, S), dtype=torch.uint8, device="cuda")
@@ -86,6 +87,6 @@ t0 = time.perf_counter(); n = 3
 for _ in range(n):
     run()
 el = time.perf_counter() - t0
-print(json.dumps({"pipeline": "YOLO-Crop+UNet (stateless detector, crop->256->project back), 256x256 canvas, 1xMI355X",
+print(json.dumps({"precision": int(os.environ.get("OG_PRECISION", "0")), "pipeline": "YOLO-Crop+UNet (stateless detector, crop->256->project back), 256x256 canvas, 1xMI355X",
                   "frames": F, "fps": round(n * F / el, 1), "frames_with_box": ndet,
                   "mask_pixels_head": [int(v) for v in (masks[:8] > 0).sum(dim=(1, 2)).tolist()]}))

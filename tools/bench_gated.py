@@ -18,6 +18,7 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 feats = (32, 64, 128, 256)
 m = og.UNet(1, 1, feats); m.load_state_dict(synth.make_unet_state_dict(feats, seed=5, head_scale=3.0, head_bias=-2.5)); m.to("cuda:0").eval()
 m.set_chunk(64)
+m.set_option("precision", int(os.environ.get("OG_PRECISION", "0")))   # 1: the opt-in split-precision kernels
 y = YoloV8Detector(synth.make_yolov8_state_dict(seed=7), device="cuda:0")
 bgr = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (F, 256, 256, 3), dtype=np.uint8)).cuda()
 gray = torch.empty((F, 256, 256), dtype=torch.uint8, device="cuda")
@@ -64,5 +65,5 @@ for _ in range(n):
         check(lib().og_yolo_detect_u8_dev(y._h, ptr(bgr[b0:]), min(256, F - b0), 256, 256, 0.25, ptr(best[b0:]), None), "yolo")
     check(lib().og_yolo_sync(y._h), "sync")
 ely = time.perf_counter() - t1
-print(json.dumps({"pipeline": "YOLO+UNet (gated), 256x256, 1xMI355X", "frames": F, "fps": round(n * F / el, 1),
+print(json.dumps({"precision": int(os.environ.get("OG_PRECISION", "0")), "pipeline": "YOLO+UNet (gated), 256x256, 1xMI355X", "frames": F, "fps": round(n * F / el, 1),
                   "yolo_only_fps": round(n * F / ely, 1), "areas_head": area[:8].tolist()}))
