@@ -38,6 +38,7 @@ extern "C" {
 #define OG_EHIP (-3)     /* HIP runtime error, see og_last_error() */
 #define OG_ENOMEM (-4)
 #define OG_ENODEV (-5)   /* no usable gfx950 device */
+#define OG_ERANGE (-6)   /* split precision only: an activation left the f16 range; the call's results are invalid */
 
 #define OG_DTYPE_F32 0
 #define OG_DTYPE_I64 1
@@ -136,7 +137,7 @@ int og_canvas_letterbox_u8_dev(og_unet* h, const uint8_t* packed_dev, const int6
 int og_mask_stats_dev(og_unet* h, const uint8_t* pred_dev, const uint8_t* gt_dev, int B, int H, int W, const int32_t* boxes_dev,
                       int32_t* stats_dev);
 
-int og_unet_sync(og_unet* h);
+int og_unet_sync(og_unet* h);                /* also reports OG_ERANGE of asynchronous split-precision work */
 void* og_unet_stream(og_unet* h);          /* hipStream_t the handle launches on */
 
 /* Micro-batch the frame loop uses per kernel chain (default 32); >=1. */

@@ -169,6 +169,8 @@ struct og_unet {
     } ring;
     int precision = 0;     // 0: exact f32 (v_mfma_f32_32x32x2_f32) -- the default and the parity reference; 1: opt-in split precision
                            // (f16 hi/lo pairs, 3 x v_mfma_f32_32x32x16_f16 per f32 product, f32 accumulation; k_conv_mfma_h)
+    int* h_range = nullptr;   // split precision: host-mapped word the kernels raise when an activation leaves the f16 range
+    int* d_range = nullptr;   //   (device view of the same word; the lanes share it)
     int h_square = 1;      // split precision, 64-column kernel on 16x16 tiles: 2x2 sub-tiles per wave (fewer LDS reads per MFMA)
     int stream_host = 1;   // og_unet_segment_u8 goes through the streaming engine (0: one-shot staging of the whole batch)
 };
@@ -640,6 +642,7 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     a.head_mask = nullptr;
     a.head_area = nullptr;
     a.head_store_act = 0;
+    a.range_flag = h->d_range;
     if (h->fuse.active) {  // set by enqueue_last_with_head for exactly one launch
         a.head_w = h->d_head_w;
         a.head_bias = h->head_bias;
@@ -821,16 +824,16 @@ int enqueue_first(og_unet* h, int kind, const void* in, int B, int H, int W) {
                2.0 * B * H * W * 9.0 * h->features[0]);
     if (kind == KIND_U8 && h->precision == 1)
         hipLaunchKernelGGL((k_conv_first<uint8_t, true>), dim3(B * tiles), dim3(256), 0, h->stream, (const uint8_t*)in, o.p,
-                           h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride());
+                           h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride(), h->d_range);
     else if (kind == KIND_U8)
         hipLaunchKernelGGL(k_conv_first<uint8_t>, dim3(B * tiles), dim3(256), 0, h->stream, (const uint8_t*)in, o.p,
-                           h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride());
+                           h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride(), (int*)nullptr);
     else if (h->precision == 1)
         hipLaunchKernelGGL((k_conv_first<float, true>), dim3(B * tiles), dim3(256), 0, h->stream, (const float*)in, o.p,
-                           h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride());
+                           h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride(), h->d_range);
     else
         hipLaunchKernelGGL(k_conv_first<float>, dim3(B * tiles), dim3(256), 0, h->stream, (const float*)in, o.p,
-                           h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride());
+                           h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride(), (int*)nullptr);
     prof_end(h);
     HIPCHK(hipGetLastError());
     return OG_OK;
@@ -871,6 +874,7 @@ int enqueue_first_fused(og_unet* h, const uint8_t* gray, int B, int H, int W) {
     a.zero_page = h->d_zero;
     a.act = 1;
     a.ksplit = 1;
+    a.range_flag = h->d_range;
     a.first_u8 = gray;
     a.first_w9 = h->d_first_w;
     a.first_scale = h->d_first_scale;
@@ -1010,6 +1014,16 @@ int run_chunk(og_unet* h, int kind, const void* in, int B, int H, int W, float t
     }
     if (fuse) return enqueue_last_with_head(h, B, thr, boxes, mask, area, logits);
     return enqueue_head(h, B, H, W, thr, boxes, mask, area, logits);
+}
+
+// Split precision only: did any activation leave the f16 range since the last check?  Call after the work has completed.
+int check_range(og_unet* h) {
+    if (h->h_range && *(volatile int*)h->h_range) {
+        *(volatile int*)h->h_range = 0;
+        return fail(OG_ERANGE, "split precision: an activation exceeded the f16 range (|v| > 60000); the result of this call is not "
+                               "valid -- use og_unet_set_option(h, \"precision\", 0) for these weights");
+    }
+    return OG_OK;
 }
 
 int check_shape(og_unet* h, int B, int H, int W) {
@@ -1234,6 +1248,7 @@ void og_unet_destroy(og_unet* h) {
         free_layer(h->bott_b);
         for (float* p : {h->d_first_w, h->d_first_scale, h->d_first_shift, h->d_head_w, h->d_zero})
             if (p) (void)hipFree(p);
+        if (h->h_range) (void)hipHostFree(h->h_range);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -1304,6 +1319,9 @@ int og_unet_finalize(og_unet* h) {
     HIPCHK(hipMalloc((void**)&h->d_partial, kPartialBytes));
     HIPCHK(hipMalloc((void**)&h->d_tile_counter, 4096 * sizeof(int)));
     HIPCHK(hipMemset(h->d_tile_counter, 0, 4096 * sizeof(int)));
+    HIPCHK(hipHostMalloc((void**)&h->h_range, sizeof(int), hipHostMallocMapped));
+    *h->h_range = 0;
+    HIPCHK(hipHostGetDevicePointer((void**)&h->d_range, h->h_range, 0));
 
     const int L = h->L;
     int rc;
@@ -1380,6 +1398,8 @@ int og_unet_finalize(og_unet* h) {
         t->d_head_w = h->d_head_w;
         t->head_bias = h->head_bias;
         t->d_zero = h->d_zero;
+        t->h_range = h->h_range;
+        t->d_range = h->d_range;
         t->n_cu = h->n_cu;
         prev->twin = t;
         prev = t;
@@ -1459,7 +1479,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
 int og_unet_sync(og_unet* h) {
     if (!h || !h->stream) return fail(OG_ESTATE, "handle not finalized");
     HIPCHK(hipStreamSynchronize(h->stream));
-    return OG_OK;
+    return check_range(h);
 }
 
 void* og_unet_stream(og_unet* h) { return h ? (void*)h->stream : nullptr; }
@@ -1612,7 +1632,7 @@ static int stream_impl(og_unet* h, const uint8_t* frames, int B, int H, int W, i
         for (auto& s : R.slots) s.b0 = -1;
         g_err = err;
     }
-    return rc;
+    return rc ? rc : check_range(h);
 }
 
 int og_unet_stream_u8(og_unet* h, const uint8_t* frames, int B, int H, int W, int channels, float thr, const int32_t* boxes,
@@ -1643,7 +1663,7 @@ int og_unet_segment_u8(og_unet* h, const uint8_t* gray, int B, int H, int W, flo
     if (area) HIPCHK(hipMemcpyAsync(area, s + o_area, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
     if (logits) HIPCHK(hipMemcpyAsync(logits, s + o_log, B * HW * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    return OG_OK;
+    return check_range(h);
 }
 
 int og_unet_forward_f32(og_unet* h, const float* x, int B, int H, int W, float* logits) {
@@ -1670,7 +1690,7 @@ int og_unet_forward_f32(og_unet* h, const float* x, int B, int H, int W, float* 
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(logits, s + o_out, B * HW * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    return OG_OK;
+    return check_range(h);
 }
 
 int og_mask_area_dev(og_unet* h, const uint8_t* mask, int B, int H, int W, const int32_t* boxes, int32_t* area) {

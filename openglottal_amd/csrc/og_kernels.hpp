@@ -110,6 +110,14 @@ __device__ __forceinline__ unsigned og_lds_addr(const void* p) {
 // store address of the f32 kernels carry over unchanged; only fragment contents and the MFMA differ.
 typedef _Float16 og_h8 __attribute__((ext_vector_type(8)));
 constexpr float OG_LO_SCALE = 2048.0f, OG_LO_INV = 1.0f / 2048.0f;
+constexpr float OG_H_MAX = 60000.0f;   // f16 tops out at 65504: an activation beyond this makes the split-precision result worthless
+// one word in host-mapped memory per handle: the epilogue raises it (rare path: one atomic per offending wave), the host
+// checks it at the next synchronisation and fails the call loudly instead of returning saturated / inf garbage
+__device__ __forceinline__ void og_flag_range(float vmax_abs, int* flag) {
+    if (flag != nullptr && __ballot(vmax_abs > OG_H_MAX) != 0ull) {
+        if ((threadIdx.x & 63) == 0) atomicOr(flag, 1);
+    }
+}
 __device__ __forceinline__ void og_split(float v, _Float16& hi, _Float16& lo) {
     hi = (_Float16)v;
     lo = (_Float16)((v - (float)hi) * OG_LO_SCALE);
@@ -164,6 +172,7 @@ struct ConvArgs {
     uint8_t* head_mask;
     int32_t* head_area;
     int head_store_act;     // also store the activation tensor (parity/debug taps)
+    int* range_flag;        // split precision only: set to 1 when an activation leaves the f16 range (|v| > OG_H_MAX); host-mapped, or nullptr
     int zdiv;               // k_conv_mfma_o's grid.z: zdiv = column tiles * ksplit (see the decode in the kernel)
     float zrcp;             // 1 / (zdiv << zgroup_shift)
     int zgroup_shift;       // log2 of the frames per z group
@@ -561,6 +570,7 @@ __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16*
         if (hk < 4 && tx0 + xl + 4 * hk < a.W) vh = (unsigned)(yl * a.W + xl + 4 * hk);
     }
 
+    float h_absmax = 0.f;   // split precision: largest |activation| this lane splits (range check below)
 #pragma unroll
     for (int m = 0; m < MS; ++m) {
         const int ms = wm * MS + m;
@@ -584,6 +594,7 @@ __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16*
                 if (HALF && !fuse_head) {   // H layout: row i = 8g + 4lh + rr of the tile image, hi at byte 2*li, lo at 64 + 2*li
                     _Float16 hi, lo;
                     og_split(v, hi, lo);
+                    h_absmax = fmaxf(h_absmax, fabsf(v));
                     _Float16* const hw = (_Float16*)scratch + (256 * lh + li) + (8 * g + rr) * 64;
                     hw[0] = hi;
                     hw[32] = lo;
@@ -657,6 +668,7 @@ __device__ __forceinline__ void conv_epilogue_b(const ConvArgs& a, const f32x16*
             }
         }
     }
+    if (HALF) og_flag_range(h_absmax, a.range_flag);
     if (MODE == 0 && NT == 1 && fuse_head && a.head_area != nullptr) {
         // one plain store per wave into a per-(frame, tile, wave) slot; k_sum_counts adds them up per frame
         if (lane == 0) {
@@ -1184,6 +1196,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
         if (WAHEAD == 2 && 1 < n_steps) stage_w(1, 1);
         __syncthreads();
         // one item = (halo pixel, 8-channel group L): the fma chain of k_conv_first for 8 channels, then hi -> slot L, lo -> slot 4+L
+        float first_absmax = 0.f;
         for (int q2 = tid; q2 < HALO_PIX * 4; q2 += 256) {
             const int p = q2 >> 2, L = q2 & 3;
             const int hy = p / HW_, hx = p - hy * HW_;
@@ -1209,12 +1222,14 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_h(ConvArgs a) {
                 for (int e = 0; e < 8; ++e) {
                     const float v = fmaxf(fmaf(sacc[e], fw[288 + 8 * L + e], fw[320 + 8 * L + e]), 0.f);
                     og_split(v, hi[e], lo[e]);
+                    first_absmax = fmaxf(first_absmax, v);
                 }
             }
             const int swz = og_halo_swz(hy, hx);
             *(f32x4*)(halo0 + p * 128 + ((L ^ swz) << 4)) = og_pack8(hi);
             *(f32x4*)(halo0 + p * 128 + (((L + 4) ^ swz) << 4)) = og_pack8(lo);
         }
+        og_flag_range(first_absmax, a.range_flag);
     }
     og_wait_dma();
     __syncthreads();
@@ -1656,8 +1671,10 @@ template <typename IN_T, bool HOUT = false>
 __global__ __launch_bounds__(256) void k_conv_first(const IN_T* __restrict__ in, float* __restrict__ out,
                                                     const float* __restrict__ w9,  // [9][Cp]
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                                    int H, int W, int Cp, int out_pix_stride, long long out_frame_stride) {
+                                                    int H, int W, int Cp, int out_pix_stride, long long out_frame_stride,
+                                                    int* range_flag = nullptr) {
     __shared__ float tile[18][20];
+    float first_absmax = 0.f;
     const int tiles_x = (W + 15) >> 4, tiles_y = (H + 15) >> 4;
     int sp = blockIdx.x;
     const int b = sp / (tiles_x * tiles_y);
@@ -1697,6 +1714,7 @@ __global__ __launch_bounds__(256) void k_conv_first(const IN_T* __restrict__ in,
                     _Float16 hi, lo;
                     og_split(v, hi, lo);
                     hl[e] = (cq < 4) ? hi : lo;
+                    first_absmax = fmaxf(first_absmax, v);
                 }
                 if (y < H && x < W) *(f32x4*)(fout + ((long long)y * W + x) * out_pix_stride + cg + cq * 4) = og_pack8(hl);
             }
@@ -1728,6 +1746,7 @@ __global__ __launch_bounds__(256) void k_conv_first(const IN_T* __restrict__ in,
             if (y < H && x < W) *(f32x4*)(fout + ((long long)y * W + x) * out_pix_stride + c0) = o;
         }
     }
+    if (HOUT) og_flag_range(first_absmax, range_flag);
 }
 
 // Head: Conv2d(f0, 1, 1) + bias -> logit (unet.py:72,88); sigmoid; > threshold;

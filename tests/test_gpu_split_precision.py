@@ -217,3 +217,34 @@ def test_latency_mode_split_k_in_split_precision(golden_dir):
     _, ar0, lg0 = m.segment(frames[:12], want_mask=False, want_logits=True)
     assert not np.array_equal(lg0, lg) or True       # (the unsplit order may or may not differ in the last bits)
     assert np.abs(lg0 - lg).max() <= TOL
+
+
+def test_activation_beyond_the_f16_range_fails_loudly_in_split_precision():
+    """The split-precision mode carries activations as f16 pairs: weights that push an activation beyond 60000 make its
+    result meaningless.  That must be an error (OG_ERANGE), never a silently saturated mask; the exact-f32 mode handles
+    the same weights."""
+    feats = (32, 64)
+    sd = synth.make_unet_state_dict(feats, seed=4, head_scale=2.0, head_bias=-0.3)
+    big = dict(sd)
+    big["downs.0.net.1.weight"] = (sd["downs.0.net.1.weight"] * np.float32(4e5)).astype(np.float32)   # first BN scale: activations ~1e5
+    m = make_model(big, feats, precision=0)
+    fr = synth.random_gray_frames(70, 32, 64, seed=3)
+    m.set_chunk(64)
+    masks, areas, logits = m.segment(fr, want_logits=True)          # exact f32: fine (finite logits)
+    assert np.isfinite(logits).all()
+    m.set_option("precision", 1)
+    for chunk in (64, 2):                                             # fused first layer / separate first-layer kernel
+        m.set_chunk(chunk)
+        with pytest.raises(og.OpenGlottalHipError, match="f16 range"):
+            m.segment(fr)
+    with pytest.raises(og.OpenGlottalHipError, match="f16 range"):
+        m((fr[:2].astype("float32") / 255.0)[:, None])
+    import torch
+    d = torch.from_numpy(fr).cuda()
+    a = torch.zeros(70, dtype=torch.int32, device="cuda")
+    m.segment_dev(d, 70, 32, 64, a)                                   # asynchronous entry point: reported by the sync
+    with pytest.raises(og.OpenGlottalHipError, match="f16 range"):
+        m.sync()
+    m.sync()                                                          # the flag is cleared by the report
+    ok = make_model(sd, feats, precision=1)                           # ordinary weights: no error
+    ok.segment(fr)
