@@ -156,7 +156,7 @@ int og_unet_set_graphs(og_unet* h, int enable);
  * "splitk_occ" 0|1 (K parts of a split launch on the occupancy kernel; 0: persistent kernel), "splitk_slots" 1..4 and "splitk_div" 1..8
  * (its target workgroups per CU / split when the launch fills less than 1/div of them),
  * "occ_min_pct" 0..400 (occupancy kernel when a launch has at least that many workgroups per 100 CUs), "convt_occ" 0|1, "fuse_first" 0|1 (first layer computed inside downs.0's second conv), "fuse_head" 0|1 (head +
- * threshold + area inside the last conv's epilogue), "keep_taps" 0|1, "stream" 0|1 (og_unet_segment_u8 through the streaming engine, default 1; 0 = whole batch staged at once), "dual" 0|1 (micro-batches of one call alternate over extra lanes = streams/arenas, so that launch tails overlap) with "lanes" 0..3 (0 = 3 lanes up to 16 frames per launch, else 2), and
+ * threshold + area inside the last conv's epilogue), "keep_taps" 0|1, "precision" 0|1 (NOT bit-identical: 0 = exact f32, the default and the parity reference; 1 = opt-in split precision -- activations and weights as f16 hi/lo pairs, three v_mfma_f32_32x32x16_f16 per f32 product, f32 accumulation; passes the reference fixtures at the f32 tolerance, 2.5x faster; an activation beyond the f16 range makes the call fail with OG_ERANGE), "h_square" 0|1 (its wave tiling), "stream" 0|1 (og_unet_segment_u8 through the streaming engine, default 1; 0 = whole batch staged at once), "dual" 0|1 (micro-batches of one call alternate over extra lanes = streams/arenas, so that launch tails overlap) with "lanes" 0..3 (0 = 3 lanes up to 16 frames per launch, else 2), and
  * "splitk" 0|1 (1 = launches that would fill < 1/4 of the chip split K across workgroups; sums
  * are taken in a fixed order, so results are deterministic but differ in the last bits from the
  * unsplit order). */
