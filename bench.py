@@ -161,11 +161,21 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # OG_BENCH_BACKEND=gloo: rehearsal of the N > 1 logic (sharding, ragged last rank, gather, max-over-ranks timing) with several
+    # ranks SHARING one GPU (RCCL refuses two ranks on one device): ranks map onto the visible devices round-robin and the tiny
+    # collectives go through host memory.  The product path and the driver's runs use nccl (= RCCL over xGMI).
+    backend = os.environ.get("OG_BENCH_BACKEND", "nccl")
+    n_dev = max(1, torch.cuda.device_count())
+    dev_index = local_rank if backend == "nccl" else local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     force_dist = os.environ.get("OG_BENCH_FORCE_DIST") == "1"  # rehearse the RCCL path on one GPU (world 1)
     if world > 1 or force_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     feats = (32, 64, 128, 256)
     sd = synth.make_unet_state_dict(feats, seed=20260227, head_scale=3.4732823371887207, head_bias=-2.890756130218506)
@@ -204,7 +214,7 @@ def main() -> None:
         if F:
             model.segment_dev(frames, F, 256, 256, area)
         model.sync()  # kernels run on the handle's stream; the collective on torch's
-        return all_gather_areas(area[:F], n_total, force=force_dist) if (world > 1 or force_dist) else area[:F]
+        return all_gather_areas(area[:F].to(coll_dev), n_total, force=force_dist) if (world > 1 or force_dist) else area[:F]
 
     def fence():
         if world > 1 or force_dist:
@@ -220,7 +230,7 @@ def main() -> None:
     fence()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     assert wave.numel() == n_total and int(wave.min()) >= 0
@@ -237,7 +247,7 @@ def main() -> None:
                                    "gray frames resident in HBM, int32 areas left on the device",
                        "frames_per_step_all_gpus": n_total, "frames_this_rank": F, "frames_per_launch": args.chunk,
                        "hip_graphs": not args.no_graphs, "lanes": args.lanes,
-                       "sharding": (f"{'one video' if strong else 'frames'} x{world} (shard_range), all_gather(int32 area) per step" if world > 1 else "none"),
+                       "sharding": (f"{'one video' if strong else 'frames'} x{world} (shard_range), all_gather(int32 area) per step over {backend}" if world > 1 else "none"),
                        "flop_per_frame": model.flops_per_frame(256, 256)},
             "tflops": round(fps * model.flops_per_frame(256, 256) / 1e12, 2),
         }
