@@ -25,6 +25,9 @@ def main(argv=None) -> int:
     r.add_argument("--device", default="cuda")
     r.add_argument("-o", "--output", default="output")
     r.add_argument("--annotate", action="store_true", help="also write the pipeline and video names into features.json")
+    r.add_argument("--precision", choices=["f32", "split"], default="f32",
+                   help="f32: exact fp32 kernels (default, the parity reference); split: opt-in f16 hi/lo split precision "
+                        "(2.5x faster, same reference fixtures and tolerance; fails loudly if an activation leaves the f16 range)")
     a = ap.parse_args(argv)
 
     import torch
@@ -36,6 +39,8 @@ def main(argv=None) -> int:
     model = UNet(1, 1, (32, 64, 128, 256)).to(a.device)
     model.load_state_dict(torch.load(a.unet_weights, map_location="cpu", weights_only=True))
     model.eval()
+    if a.precision == "split":
+        model.set_option("precision", 1)
     detector = TemporalDetector(a.yolo_weights) if a.pipeline == "unet" else None
     feats = extract_features_unet(a.video, detector, model, a.device)
     if feats is None:
