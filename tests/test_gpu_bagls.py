@@ -114,3 +114,55 @@ def test_evaluate_device_equals_host_orchestrated_evaluate(trained, tmp_path):
         assert set(got[p]) == {"dice", "iou", "n_det", "n_total"} and len(got[p]["dice"]) == got[p]["n_total"] == 61
     assert got["_meta"]["crop_letterbox"] is True
     E.print_table(agg_d)
+
+
+def _c5_rank(rank, world, port, n, q):
+    """One rank of the sharded BAGLS evaluation: own process, own handles on the (shared) GPU, gloo for the gather."""
+    import torch.distributed as dist
+
+    from openglottal_amd.dist import shard_range, sharded_eval_counts
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_trained_small.npz"))
+    sd = {k[2:]: g[k] for k in g.files if k.startswith("W:")}
+    m = og.UNet(1, 1, tuple(int(f) for f in g["features"]))
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    det = og.TemporalDetector(YoloV8Detector(synth.make_yolov8_state_dict(seed=7, cls_bias=1.0), device="cuda:0"), conf=0.25)
+    frames, gts = synth.bagls_standin(n, seed=5)
+    counts = sharded_eval_counts(n, lambda lo, hi: E.evaluate_counts_device(frames[lo:hi], gts[lo:hi], m, det, None, 256, 0), rank, world)
+    q.put((rank, counts.tolist()))
+    dist.destroy_process_group()
+
+
+def test_c5_sharded_over_two_ranks_equals_single_process(trained):
+    """BASELINE config C5 sharded (here: two processes sharing the one GPU, gloo for the 40-byte-per-frame gather): every
+    rank ends with the whole per-frame count table, equal to the single-process one, hence the same three-row table."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    m = trained
+    n = 37
+    frames, gts = synth.bagls_standin(n, seed=5)
+    det = og.TemporalDetector(YoloV8Detector(synth.make_yolov8_state_dict(seed=7, cls_bias=1.0), device="cuda:0"), conf=0.25)
+    ref = E.evaluate_counts_device(frames, gts, m, det, None, 256, 0)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_c5_rank, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(120)
+    assert sorted(r[0] for r in res) == [0, 1]
+    for rank, counts in res:
+        assert np.array_equal(np.array(counts), ref), rank
+    agg, st = E.agg_from_counts(ref, True, True)
+    agg1, st1 = E.evaluate_device(frames, gts, m, det, None, 256, 0)
+    assert st == st1 and all(agg[p]["dice"] == agg1[p]["dice"] for p in E.PIPELINES)
