@@ -250,82 +250,84 @@ def evaluate_counts_device(frames, gts, unet_model, detector=None, crop_model=No
 
     pool = ThreadPoolExecutor(1)   # packs block k+1 on the host while the device works on block k
     nxt = pool.submit(prepare, 0)
-    for lo in range(0, n, block):
-        B, bgr, rec_f, rec_g = nxt.result()
-        if lo + block < n:
-            nxt = pool.submit(prepare, lo + block)
-        img = letterbox_dev(rec_f, B, 3 if bgr else 1)                 # img_lb  (eval_bagls.py:153)
-        gt = letterbox_dev(rec_g, B, 1)                                 # gt_lb   (:154)
-        if bgr:
-            gray = torch.empty((B, S, S), dtype=torch.uint8, device=dev)
-            unet_model.bgr2gray_dev(img, B, S, S, gray)                 # gray_lb (:155)
-        else:
-            gray = img
-        boxes = [None] * B
-        if detector is not None:
-            if native:
-                bgr_in = img if bgr else gray[..., None].expand(B, S, S, 3).contiguous()
-                unet_model.sync()
-                best = detector.model.detect_dev(bgr_in, B, S, S, detector.conf)
-            for i in range(B):
-                detector.reset()                                        # :164-166: BAGLS frames are not a sequence
+    try:
+        for lo in range(0, n, block):
+            B, bgr, rec_f, rec_g = nxt.result()
+            if lo + block < n:
+                nxt = pool.submit(prepare, lo + block)
+            img = letterbox_dev(rec_f, B, 3 if bgr else 1)                 # img_lb  (eval_bagls.py:153)
+            gt = letterbox_dev(rec_g, B, 1)                                 # gt_lb   (:154)
+            if bgr:
+                gray = torch.empty((B, S, S), dtype=torch.uint8, device=dev)
+                unet_model.bgr2gray_dev(img, B, S, S, gray)                 # gray_lb (:155)
+            else:
+                gray = img
+            boxes = [None] * B
+            if detector is not None:
                 if native:
-                    boxes[i] = detector.update(best[i:i + 1, :4], best[i:i + 1, 4], S, S) if best[i, 4] >= 0 else detector.update(None, None, S, S)
-                else:
-                    f_host = img[i].cpu().numpy()
-                    boxes[i] = detector.detect(f_host if bgr else np.repeat(f_host[..., None], 3, axis=-1))
-        mask_u = torch.empty((B, S, S), dtype=torch.uint8, device=dev)
-        area_u = torch.empty(B, dtype=torch.int32, device=dev)
-        unet_model.segment_dev(gray, B, S, S, area_u, mask_dev=mask_u)
-        st_u = torch.empty((B, 3), dtype=torch.int32, device=dev)
-        check(lib().og_mask_stats_dev(unet_model._h, ptr(mask_u), ptr(gt), B, S, S, None, ptr(st_u)), "og_mask_stats_dev")
-        res = np.zeros((B, 10), np.int64)
-        if detector is not None:
-            nb = np.array([normalize_box(b, S, S) for b in boxes], np.int32)          # python-slice semantics of mask[y1:y2, x1:x2]
-            d_nb = up(nb)
-            st_yu = torch.empty((B, 3), dtype=torch.int32, device=dev)
-            check(lib().og_mask_stats_dev(unet_model._h, ptr(mask_u), ptr(gt), B, S, S, ptr(d_nb), ptr(st_yu)), "og_mask_stats_dev")
-            clamp = np.array([(-1, -1, -1, -1) if b is None else (max(0, min(S, int(b[0]))), max(0, min(S, int(b[1]))),
-                                                                  max(0, min(S, int(b[2]))), max(0, min(S, int(b[3])))) for b in boxes], np.int32)
-            d_cl = up(clamp)                                            # :181-186 clamp for the TP/FP bookkeeping
-            gt_in = torch.empty(B, dtype=torch.int32, device=dev)
-            unet_model.mask_area_dev(gt, B, S, S, d_cl, gt_in)
-            # yolo-crop+unet (:89-112, :209-222): optional crop_pad, crop, letterbox NEAREST, U-Net, project back, paste
-            cb = np.full((B, 4), -1, np.int32)
-            geo = np.zeros((B, 4), np.int32)
-            for i, b in enumerate(boxes):
-                if b is None:
-                    continue
-                x1, y1, x2, y2 = (int(v) for v in b)
-                if crop_pad:
-                    x1, y1, x2, y2 = max(0, x1 - crop_pad), max(0, y1 - crop_pad), min(S, x2 + crop_pad), min(S, y2 + crop_pad)
-                x1, y1, x2, y2 = normalize_box((x1, y1, x2, y2), S, S)
-                if x2 - x1 <= 0 or y2 - y1 <= 0:
-                    continue
-                cb[i] = (x1, y1, x2, y2)
-                geo[i] = letterbox_geometry(y2 - y1, x2 - x1, NET_SIZE)
-            d_cb, d_geo = up(cb), up(geo)
-            tiles = torch.empty((B, NET_SIZE, NET_SIZE), dtype=torch.uint8, device=dev)
-            tmask = torch.empty_like(tiles)
-            mask_c = torch.empty((B, S, S), dtype=torch.uint8, device=dev)
+                    bgr_in = img if bgr else gray[..., None].expand(B, S, S, 3).contiguous()
+                    unet_model.sync()
+                    best = detector.model.detect_dev(bgr_in, B, S, S, detector.conf)
+                for i in range(B):
+                    detector.reset()                                        # :164-166: BAGLS frames are not a sequence
+                    if native:
+                        boxes[i] = detector.update(best[i:i + 1, :4], best[i:i + 1, 4], S, S) if best[i, 4] >= 0 else detector.update(None, None, S, S)
+                    else:
+                        f_host = img[i].cpu().numpy()
+                        boxes[i] = detector.detect(f_host if bgr else np.repeat(f_host[..., None], 3, axis=-1))
+            mask_u = torch.empty((B, S, S), dtype=torch.uint8, device=dev)
+            area_u = torch.empty(B, dtype=torch.int32, device=dev)
+            unet_model.segment_dev(gray, B, S, S, area_u, mask_dev=mask_u)
+            st_u = torch.empty((B, 3), dtype=torch.int32, device=dev)
+            check(lib().og_mask_stats_dev(unet_model._h, ptr(mask_u), ptr(gt), B, S, S, None, ptr(st_u)), "og_mask_stats_dev")
+            res = np.zeros((B, 10), np.int64)
+            if detector is not None:
+                nb = np.array([normalize_box(b, S, S) for b in boxes], np.int32)          # python-slice semantics of mask[y1:y2, x1:x2]
+                d_nb = up(nb)
+                st_yu = torch.empty((B, 3), dtype=torch.int32, device=dev)
+                check(lib().og_mask_stats_dev(unet_model._h, ptr(mask_u), ptr(gt), B, S, S, ptr(d_nb), ptr(st_yu)), "og_mask_stats_dev")
+                clamp = np.array([(-1, -1, -1, -1) if b is None else (max(0, min(S, int(b[0]))), max(0, min(S, int(b[1]))),
+                                                                      max(0, min(S, int(b[2]))), max(0, min(S, int(b[3])))) for b in boxes], np.int32)
+                d_cl = up(clamp)                                            # :181-186 clamp for the TP/FP bookkeeping
+                gt_in = torch.empty(B, dtype=torch.int32, device=dev)
+                unet_model.mask_area_dev(gt, B, S, S, d_cl, gt_in)
+                # yolo-crop+unet (:89-112, :209-222): optional crop_pad, crop, letterbox NEAREST, U-Net, project back, paste
+                cb = np.full((B, 4), -1, np.int32)
+                geo = np.zeros((B, 4), np.int32)
+                for i, b in enumerate(boxes):
+                    if b is None:
+                        continue
+                    x1, y1, x2, y2 = (int(v) for v in b)
+                    if crop_pad:
+                        x1, y1, x2, y2 = max(0, x1 - crop_pad), max(0, y1 - crop_pad), min(S, x2 + crop_pad), min(S, y2 + crop_pad)
+                    x1, y1, x2, y2 = normalize_box((x1, y1, x2, y2), S, S)
+                    if x2 - x1 <= 0 or y2 - y1 <= 0:
+                        continue
+                    cb[i] = (x1, y1, x2, y2)
+                    geo[i] = letterbox_geometry(y2 - y1, x2 - x1, NET_SIZE)
+                d_cb, d_geo = up(cb), up(geo)
+                tiles = torch.empty((B, NET_SIZE, NET_SIZE), dtype=torch.uint8, device=dev)
+                tmask = torch.empty_like(tiles)
+                mask_c = torch.empty((B, S, S), dtype=torch.uint8, device=dev)
+                unet_model.sync()
+                check(lib().og_unet_segment_crops_u8_dev(cm._h, ptr(gray), B, S, S, ptr(d_cb), ptr(d_geo), NET_SIZE, 0.5, ptr(tiles), ptr(tmask),
+                                                         ptr(mask_c)), "og_unet_segment_crops_u8_dev")
+                cm.sync()
+                st_c = torch.empty((B, 3), dtype=torch.int32, device=dev)
+                check(lib().og_mask_stats_dev(unet_model._h, ptr(mask_c), ptr(gt), B, S, S, None, ptr(st_c)), "og_mask_stats_dev")
+                unet_model.sync()
+                yu, c, gin = st_yu.cpu().numpy(), st_c.cpu().numpy(), gt_in.cpu().numpy()
+                res[:, 3:5] = yu[:, :2]
+                res[:, 5:7] = c[:, :2]
+                res[:, 7] = [b is not None for b in boxes]
+                res[:, 8] = gin > 0
             unet_model.sync()
-            check(lib().og_unet_segment_crops_u8_dev(cm._h, ptr(gray), B, S, S, ptr(d_cb), ptr(d_geo), NET_SIZE, 0.5, ptr(tiles), ptr(tmask),
-                                                     ptr(mask_c)), "og_unet_segment_crops_u8_dev")
-            cm.sync()
-            st_c = torch.empty((B, 3), dtype=torch.int32, device=dev)
-            check(lib().og_mask_stats_dev(unet_model._h, ptr(mask_c), ptr(gt), B, S, S, None, ptr(st_c)), "og_mask_stats_dev")
-            unet_model.sync()
-            yu, c, gin = st_yu.cpu().numpy(), st_c.cpu().numpy(), gt_in.cpu().numpy()
-            res[:, 3:5] = yu[:, :2]
-            res[:, 5:7] = c[:, :2]
-            res[:, 7] = [b is not None for b in boxes]
-            res[:, 8] = gin > 0
-        unet_model.sync()
-        u = st_u.cpu().numpy()
-        res[:, 0:3] = u
-        res[:, 9] = u[:, 2] > 0
-        out[lo:lo + B] = res
-    pool.shutdown()
+            u = st_u.cpu().numpy()
+            res[:, 0:3] = u
+            res[:, 9] = u[:, 2] > 0
+            out[lo:lo + B] = res
+    finally:
+        pool.shutdown()
     return out
 
 
