@@ -109,7 +109,8 @@ struct og_unet {
     int xcd_group = 1;   // see LaunchCtx::xcd_group
     int splitk_occ = 1;  // split-K parts on the occupancy kernel (0: persistent kernel)
     int splitk_min_steps = 9;  // smallest K part of a split 3x3 conv, in (chunk, tap) steps (9 = one channel chunk)
-    int splitk_slots = 2, splitk_div = 4;  // occupancy split-K: target workgroups per CU; split when the launch fills < 1/div of them
+    int splitk_slots = 1, splitk_div = 2;  // occupancy split-K: target workgroups per CU; split when the launch fills < 1/div of them
+                                           // (round-2 sweep, one to three lanes, both precisions: 1 / 2 beats round 1's 2 / 4 at 1-4 frames per launch)
     int occ_min_pct = 100; // occupancy kernel when workgroups >= pct % of the CU count (0: one full round of 2-3 per CU);
                            // measured 25..300 at 2..32 frames per launch: 100 is best or within 1 % everywhere
     int tps_nt2 = 1;     // taps per step for the 64-column kernel
