@@ -204,6 +204,11 @@ og_yolo* og_yolo_create(int nc);                      /* nc: number of classes (
 void og_yolo_destroy(og_yolo* h);
 int og_yolo_set_tensor(og_yolo* h, const char* key, const void* host, const int64_t* shape, int ndim, int dtype);
 int og_yolo_finalize(og_yolo* h);
+/* Tuning knobs (defaults in brackets).  "latency_batch" [1]: calls of at most this many frames (the reference's
+ * one-frame-per-call pattern, detector.py:58) take the latency path -- convs that would leave most of the chip idle split
+ * K over workgroups, so their float sums are ordered differently from the batched path (results agree to rounding; 0 turns
+ * the path off and makes every call bit-identical to the batched one).  "splitk_slots" [1], "splitk_div" [2]: as og_unet's. */
+int og_yolo_set_option(og_yolo* h, const char* name, int value);
 int og_yolo_num_anchors(og_yolo* h, int H, int W);    /* (H/8)(W/8)+(H/16)(W/16)+(H/32)(W/32) */
 /* frames [B,H,W,3] u8 BGR at network resolution (H,W multiples of 32; the caller letterboxes).
  *   best [B,5] f32: x1,y1,x2,y2,conf of the arg-max-confidence candidate with conf > conf_thres,

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "og_yolo_destroy": (None, [C.c_void_p]),
     "og_yolo_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_int]),
     "og_yolo_finalize": (C.c_int, [C.c_void_p]),
+    "og_yolo_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "og_yolo_num_anchors": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "og_yolo_detect_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "og_yolo_detect_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),

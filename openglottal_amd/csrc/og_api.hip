@@ -469,7 +469,8 @@ int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     static_assert(lds >= 4 * 5120, "the epilogue's per-wave scratch needs 20 KB");
     ConvArgs a = a_in;
     a.stamps = nullptr;  // the probe buffer is sized for the persistent kernel's grid; this kernel's timeline is tools/ubench/occ_timeline
-    if (MODE != 0 && MODE != 1) a.ksplit = 1;
+    if (a.n_spatial * n_ntiles > 4096) a.tile_counter = nullptr;
+    if ((MODE == 2 || MODE == 3) && a.tile_counter == nullptr) a.ksplit = 1;   // these modes split K with the fused reduce only
     const int frames = a.n_spatial / (a.tiles_x * a.tiles_y);
     a.zdiv = n_ntiles * a.ksplit;
     a.frames = frames;
@@ -483,12 +484,14 @@ int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     const int G = 1 << a.zgroup_shift, groups = (frames + G - 1) / G;
     a.zrcp = 1.0f / (float)(a.zdiv * G);
     if ((long long)groups * G * a.zdiv > 65535) return fail(OG_EINVAL, "micro-batch too large for one launch (grid.z): lower the chunk size");
-    if (a.ksplit == 1 || a.n_spatial * n_ntiles > 4096) a.tile_counter = nullptr;
+    if (a.ksplit == 1) a.tile_counter = nullptr;
     hipLaunchKernelGGL((k_conv_mfma_o<NT, MODE, TH, OCC>), dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), lds, c.stream, a);
     HIPCHK(hipGetLastError());
-    if (a.ksplit > 1 && a.tile_counter == nullptr) {
-        hipLaunchKernelGGL((k_splitk_epilogue<NT, MODE, TH>), dim3(a.n_spatial * n_ntiles), dim3(256), 4 * 5120, c.stream, a);
-        HIPCHK(hipGetLastError());
+    if constexpr (MODE == 0 || MODE == 1) {
+        if (a.ksplit > 1 && a.tile_counter == nullptr) {
+            hipLaunchKernelGGL((k_splitk_epilogue<NT, MODE, TH>), dim3(a.n_spatial * n_ntiles), dim3(256), 4 * 5120, c.stream, a);
+            HIPCHK(hipGetLastError());
+        }
     }
     return OG_OK;
 }

@@ -750,7 +750,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     // ---- tile decode (scalar).  3-D grid (tile column, tile row, frame x column tile x K part): no integer division
     //      on the way to the first DMA (each one is ~20 vector-ALU instructions, paid at the contended issue rate).
     //      split-K (latency mode, MODE 0/1): K part = a range of (chunk, tap) steps ----
-    const int ks_n = (MODE == 0 || MODE == 1) ? a.ksplit : 1;
+    const int ks_n = a.ksplit;
     // grid.z = frame group q x (column tile, K part) x frame-in-group: the column tiles of one spatial tile then sit
     // G * tiles_x * tiles_y (a multiple of 8) blocks apart = on the same XCD, dispatched together, and share the input
     // tile in that XCD's L2 (G = 2^zgroup_shift frames per group; 1 when tiles_x * tiles_y is already a multiple of 8)
@@ -763,11 +763,27 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     if (b >= a.frames) return;   // tail of the last frame group (whole workgroup, before any barrier)
     const int n_tile = (ks_n == 1) ? zr : zr / ks_n;
     const int kpart = (ks_n == 1) ? 0 : zr - n_tile * ks_n;
+    // K parts: ranges of (chunk, tap) steps for the 3x3 conv, of whole chunks elsewhere.  MODE 3 (virtual chunk =
+    // (input-pixel parity, 32-channel chunk), 1 / 2 / 2 / 4 non-zero taps per parity): parts are ranges of virtual chunks
     constexpr int TAPS_ = (MODE == 0) ? 9 : 1;
-    const int s_lo = (ks_n == 1) ? 0 : (kpart * a.n_chunks * TAPS_) / ks_n;
-    const int s_hi = (ks_n == 1) ? a.n_chunks * TAPS_ : ((kpart + 1) * a.n_chunks * TAPS_) / ks_n;
-    const int c_lo = (ks_n == 1) ? 0 : s_lo / TAPS_;
-    const int c_hi = (ks_n == 1) ? a.n_chunks : (s_hi + TAPS_ - 1) / TAPS_;
+    const int cpc = (MODE == 3) ? a.n_chunks >> 2 : 1;
+    auto steps_before = [&](int c) {   // MODE 3: weight steps that precede virtual chunk c
+        const int par = c / cpc;
+        const int before = (par == 0) ? 0 : (par == 1) ? 1 : (par == 2) ? 3 : (par == 3) ? 5 : 9;
+        return before * cpc + (c - par * cpc) * ((1 + (par >> 1)) * (1 + (par & 1)));
+    };
+    int s_lo, s_hi, c_lo, c_hi;
+    if (MODE == 3) {
+        c_lo = (ks_n == 1) ? 0 : (kpart * a.n_chunks) / ks_n;
+        c_hi = (ks_n == 1) ? a.n_chunks : ((kpart + 1) * a.n_chunks) / ks_n;
+        s_lo = (ks_n == 1) ? 0 : steps_before(c_lo);
+        s_hi = (ks_n == 1) ? cpc * 9 : steps_before(c_hi);
+    } else {
+        s_lo = (ks_n == 1) ? 0 : (kpart * a.n_chunks * TAPS_) / ks_n;
+        s_hi = (ks_n == 1) ? a.n_chunks * TAPS_ : ((kpart + 1) * a.n_chunks * TAPS_) / ks_n;
+        c_lo = (ks_n == 1) ? 0 : s_lo / TAPS_;
+        c_hi = (ks_n == 1) ? a.n_chunks : (s_hi + TAPS_ - 1) / TAPS_;
+    }
     const int ty0 = (int)blockIdx.y * TH;
     const int tx0 = (int)blockIdx.x * TW;
     // linear ids (split-K partial buffer, diagnostic stamps): as k_splitk_epilogue decodes them
@@ -803,7 +819,6 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     const unsigned lds0 = og_lds_addr(smem);
     // MODE 3 (3x3 stride-2 conv as a 2x2 stride-1 conv over the space-to-depth view, never materialised):
     // virtual chunk c = (input-pixel parity par = c / cpc, 32-channel chunk c % cpc)
-    const int cpc = (MODE == 3) ? a.n_chunks >> 2 : 1;
     auto stage_halo = [&](int buf, int c) {
         const unsigned base = lds0 + wave * 1024;
         (void)buf;
@@ -926,11 +941,11 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(0);
 
     int step = s_lo;                             // absolute (chunk, tap) index: also the weight block's index
-    const int step_end = (MODE == 3) ? total_steps : s_hi;
+    const int step_end = s_hi;
     for (int c = c_lo; c < c_hi; ++c) {
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
-            if ((MODE == 0 || MODE == 1) && ks_n > 1 && (c * TAPS + t < s_lo || c * TAPS + t >= s_hi)) continue;  // another K part's step
+            if (MODE == 0 && ks_n > 1 && (c * TAPS + t < s_lo || c * TAPS + t >= s_hi)) continue;  // another K part's step
             if (MODE == 3) {  // tap (ty,tx) of the 2x2 kernel meets parity (py,px): zero unless (ty==1 || py==1) and (tx==1 || px==1)
                 const int par = c / cpc;
                 if (((t >> 1) == 0 && (par & 2) == 0) || ((t & 1) == 0 && (par & 1) == 0)) continue;
@@ -998,16 +1013,32 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
                 for (int m = 0; m < MS; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-                for (int sp_ = 0; sp_ < ks_n; ++sp_) {
-                    const float* pr = a.partial + (((long long)tile_id * ks_n + sp_) * 4 + wave) * (MS * 16 * 64) + lane;
+                // parts are fetched PG at a time (all their loads in flight together: one memory round trip per group
+                // instead of one per part) and added in split order; PG = 1 on the 16-row tiles keeps that kernel's registers
+                constexpr int PG = (MS == 1) ? 4 : (MS == 2) ? 2 : 1;
+                for (int sp_ = 0; sp_ < ks_n; sp_ += PG) {
+                    float pv[PG][MS * 16];
 #pragma unroll
-                    for (int m = 0; m < MS; ++m)
+                    for (int g = 0; g < PG; ++g) {
+                        const int sg = (sp_ + g < ks_n) ? sp_ + g : sp_;   // tail: re-read a live part, not added below
+                        const float* pr = a.partial + (((long long)tile_id * ks_n + sg) * 4 + wave) * (MS * 16 * 64) + lane;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[m][r] += __hip_atomic_load(pr + (m * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int k = 0; k < MS * 16; ++k) pv[g][k] = __hip_atomic_load(pr + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int g = 0; g < PG; ++g)
+                        if (sp_ + g < ks_n) {
+#pragma unroll
+                            for (int m = 0; m < MS; ++m)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[m][r] += pv[g][m * 16 + r];
+                        }
                 }
                 __syncthreads();   // the flag word is part of wave 0's scratch
                 unsigned char* const scr = smem + wave * 5120;
                 if (a.act == 1) conv_epilogue_b<NT, MODE, TH, 1, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+                else if (a.act == 2 && a.res != nullptr) conv_epilogue_b<NT, MODE, TH, 2, true>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+                else if (a.act == 2) conv_epilogue_b<NT, MODE, TH, 2, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
                 else conv_epilogue_b<NT, MODE, TH, 0, false>(a, acc, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
                 if (tid == 0) a.tile_counter[tile_id] = 0;   // ready for the next launch on this stream
             }
@@ -1861,40 +1892,41 @@ __global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t* __restrict__ bg
 // predictor's BGR->RGB swap and /255 fused).  Used for the seven stride-2 convs (~15 % of the
 // detector's MACs); 8 lanes per output pixel x 4 output channels each.
 // Weights: [k*k][Cin][Cout_p] (Cout contiguous).
-template <bool IN_U8>
+template <bool IN_U8, int PX = 4>
 __global__ __launch_bounds__(256) void k_conv_direct(const void* __restrict__ in_, long long in_frame_stride, int in_pix_stride,
                                                      int in_ch_off, int Hin, int Win, int Cin, const float* __restrict__ w,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      int Cout_p, float* __restrict__ out, long long out_frame_stride,
                                                      int out_pix_stride, int out_ch_off, int Hout, int Wout, int ks, int stride,
-                                                     int pad, int act, int total_quads /* B*Hout*ceil(Wout/4) */,
+                                                     int pad, int act, int total_quads /* B*Hout*ceil(Wout/PX) */,
                                                      int cq_shift /* log2(channel quads worked on per 32-channel group): 3 = all
                                                                      eight; 2 when only 16 of the 32 padded channels are real, ... */) {
-    // thread = (4 consecutive output pixels along x) x (4 output channels): 16 accumulators, so one
+    // thread = (PX = 4 consecutive output pixels along x) x (4 output channels): 16 accumulators, so one
     // weight float4 and four input values feed 16 FMAs (the first version did 4 FMAs per 2 loads).
+    // PX = 1 (one-frame calls): four times the threads, a quarter of the serial loads each; same fma chain per output.
     // Padded output channels (zero weights; their slots stay at the arena's initial zeros) get no thread at all.
     const int cq = threadIdx.x & ((1 << cq_shift) - 1);
     const int q = (blockIdx.x * 256 + threadIdx.x) >> cq_shift;
     if (q >= total_quads) return;
-    const int qpr = (Wout + 3) >> 2;  // quads per output row
+    const int qpr = (Wout + PX - 1) / PX;  // quads per output row
     const int row = q / qpr;
-    const int ox0 = (q - row * qpr) * 4;
+    const int ox0 = (q - row * qpr) * PX;
     const int b = row / Hout;
     const int oy = row - b * Hout;
     {
         const int c0 = blockIdx.y * 32 + cq * 4;  // one 32-channel output group per blockIdx.y: small maps still fill the chip
-        f32x4 acc[4];
+        f32x4 acc[PX];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < PX; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int ky = 0; ky < ks; ++ky) {
             const int iy = oy * stride - pad + ky;
             if (iy < 0 || iy >= Hin) continue;
             for (int kx = 0; kx < ks; ++kx) {
                 const float* wp = w + (long long)((ky * ks + kx) * Cin) * Cout_p + c0;
-                int ix[4];
-                bool ok[4];
+                int ix[PX];
+                bool ok[PX];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < PX; ++j) {
                     ix[j] = (ox0 + j) * stride - pad + kx;
                     ok[j] = ix[j] >= 0 && ix[j] < Win && (ox0 + j) < Wout;
                 }
@@ -1904,7 +1936,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const void* __restrict__ in
                     for (int ci = 0; ci < 3; ++ci) {
                         const f32x4 wv = *(const f32x4*)(wp + ci * Cout_p);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
+                        for (int j = 0; j < PX; ++j) {
                             const float xv = ok[j] ? (float)rowp[ix[j] * 3 + 2 - ci] / 255.0f : 0.f;  // RGB[ci] = BGR[2-ci]
                             acc[j].x = fmaf(xv, wv.x, acc[j].x);
                             acc[j].y = fmaf(xv, wv.y, acc[j].y);
@@ -1915,16 +1947,16 @@ __global__ __launch_bounds__(256) void k_conv_direct(const void* __restrict__ in
                 } else {
                     const float* rowp = (const float*)in_ + (long long)b * in_frame_stride + (long long)iy * Win * in_pix_stride + in_ch_off;
                     for (int ci = 0; ci < Cin; ci += 4) {
-                        f32x4 xv[4];
+                        f32x4 xv[PX];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                        for (int j = 0; j < PX; ++j)
                             xv[j] = ok[j] ? *(const f32x4*)(rowp + (long long)ix[j] * in_pix_stride + ci) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             if (ci + e < Cin) {
                                 const f32x4 wv = *(const f32x4*)(wp + (long long)(ci + e) * Cout_p);
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) {
+                                for (int j = 0; j < PX; ++j) {
                                     acc[j].x = fmaf(xv[j][e], wv.x, acc[j].x);
                                     acc[j].y = fmaf(xv[j][e], wv.y, acc[j].y);
                                     acc[j].z = fmaf(xv[j][e], wv.z, acc[j].z);
@@ -1939,7 +1971,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const void* __restrict__ in
         const f32x4 sc = *(const f32x4*)(scale + c0);
         const f32x4 sh = *(const f32x4*)(shift + c0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PX; ++j) {
             if (ox0 + j < Wout) {
                 f32x4 o;
                 o.x = og_act(fmaf(acc[j].x, sc.x, sh.x), act);
@@ -1978,6 +2010,45 @@ __global__ __launch_bounds__(256) void k_maxpool5(const float* __restrict__ buf_
         }
     }
     *(f32x4*)(buf_out + b * frame_stride + ((long long)y * W + x) * pix_stride + out_off + c) = m;
+}
+
+// SPPF's three chained 5x5 pools in ONE launch (one-frame calls on small maps): a workgroup keeps a 32-channel slab of the
+// whole map in LDS and pools it three times (segment j -> segment j+1 of the concat buffer, j = 0..2).  max() is exact, so
+// the result is the chain's, value for value.  LDS: 2 x H*W*128 B (host checks H*W <= 224).
+__global__ __launch_bounds__(256) void k_sppf_pools(float* __restrict__ buf, long long frame_stride, int pix_stride, int seg /*channels per segment*/,
+                                                    int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4* cur = (f32x4*)smem;
+    f32x4* nxt = cur + H * W * 8;
+    const int slab = blockIdx.x, b = blockIdx.y, n = H * W * 8;
+    float* base = buf + (long long)b * frame_stride + slab * 32;
+    for (int i = threadIdx.x; i < n; i += 256) cur[i] = *(const f32x4*)(base + (long long)(i >> 3) * pix_stride + (i & 7) * 4);
+    __syncthreads();
+    for (int j = 1; j <= 3; ++j) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int p = i >> 3, q = i & 7, y = p / W, x = p - y * W;
+            f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            for (int dy = -2; dy <= 2; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= H) continue;
+                for (int dx = -2; dx <= 2; ++dx) {
+                    const int xx = x + dx;
+                    if (xx < 0 || xx >= W) continue;
+                    const f32x4 v = cur[(yy * W + xx) * 8 + q];
+                    m.x = fmaxf(m.x, v.x);
+                    m.y = fmaxf(m.y, v.y);
+                    m.z = fmaxf(m.z, v.z);
+                    m.w = fmaxf(m.w, v.w);
+                }
+            }
+            nxt[i] = m;
+            *(f32x4*)(base + (long long)p * pix_stride + j * seg + q * 4) = m;
+        }
+        __syncthreads();
+        f32x4* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
 }
 
 // nn.Upsample(scale_factor=2, mode="nearest"): out[y][x] = in[y/2][x/2], into a channel segment.
@@ -2101,6 +2172,144 @@ __global__ __launch_bounds__(256) void k_yolo_decode(YoloDecodeArgs a) {
     } else if (best_i == win && best_c == s_conf[0]) {
         float* o = a.best + (long long)b * 5;
         o[0] = bx[0]; o[1] = bx[1]; o[2] = bx[2]; o[3] = bx[3]; o[4] = best_c;
+    }
+}
+
+// One-frame calls: the same decode spread over ceil(A / 64) workgroups per frame -- thread = (anchor, box side), so a
+// thread reads 16 DFL logits instead of 64 and 21 workgroups work instead of one.  Per-anchor arithmetic is the single-
+// workgroup kernel's, expression for expression; every workgroup leaves its best candidate in `cand`, the last one to
+// arrive (arrival counter, reset for the next launch) picks the winner by (confidence, lowest index), as above.
+__global__ __launch_bounds__(256) void k_yolo_decode_mb(YoloDecodeArgs a, float* __restrict__ cand /*[B][nblk][8]*/, int* __restrict__ counter /*[B]*/) {
+    __shared__ float s_conf[64];
+    __shared__ int s_idx[64];
+    __shared__ int s_last;
+    const int b = blockIdx.y, nblk = gridDim.x;
+    const int la = threadIdx.x >> 2, sd = threadIdx.x & 3;
+    const int i = blockIdx.x * 64 + la;
+    float conf = -1.f;
+    float r[4] = {0, 0, 0, 0};
+    bool cand_ok = false;
+    {
+        const bool live = i < a.n_anchors;
+        int l = 0, j = live ? i : 0;
+        if (j >= a.lv[0].h * a.lv[0].w) {
+            j -= a.lv[0].h * a.lv[0].w;
+            l = 1;
+            if (j >= a.lv[1].h * a.lv[1].w) {
+                j -= a.lv[1].h * a.lv[1].w;
+                l = 2;
+            }
+        }
+        const YoloLevel& L = a.lv[l];
+        const int y = j / L.w, x = j - y * L.w;
+        const float* bp = L.box + (long long)b * L.box_frame_stride + (long long)j * L.box_pix_stride;
+        float v[16], mx = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            v[q] = bp[sd * 16 + q];
+            mx = fmaxf(mx, v[q]);
+        }
+        float se = 0.f, sw = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float e = expf(v[q] - mx);
+            se += e;
+            sw += e * (float)q;
+        }
+        const float dmine = sw / se;
+        float d[4];
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) d[s_] = __shfl(dmine, (threadIdx.x & 60) + s_, 64);
+        const float ax = (float)x + 0.5f, ay = (float)y + 0.5f;
+        const float x1a = ax - d[0], y1a = ay - d[1], x2a = ax + d[2], y2a = ay + d[3];
+        const float cx = (x1a + x2a) * 0.5f * L.stride, cy = (y1a + y2a) * 0.5f * L.stride;
+        const float ww = (x2a - x1a) * L.stride, hh = (y2a - y1a) * L.stride;
+        const float lg = L.cls[(long long)b * L.cls_frame_stride + (long long)j * L.cls_pix_stride];
+        const float cf = 1.0f / (1.0f + expf(-lg));
+        r[0] = cx - ww * 0.5f; r[1] = cy - hh * 0.5f; r[2] = cx + ww * 0.5f; r[3] = cy + hh * 0.5f;
+        r[0] = fminf(fmaxf(r[0], 0.f), a.img_w);
+        r[2] = fminf(fmaxf(r[2], 0.f), a.img_w);
+        r[1] = fminf(fmaxf(r[1], 0.f), a.img_h);
+        r[3] = fminf(fmaxf(r[3], 0.f), a.img_h);
+        if (live && sd == 0) {
+            if (a.pred) {
+                float* pp = a.pred + ((long long)b * a.n_anchors + i) * 5;
+                pp[0] = r[0]; pp[1] = r[1]; pp[2] = r[2]; pp[3] = r[3]; pp[4] = cf;
+            }
+            if (cf > a.conf_thres) {
+                conf = cf;
+                cand_ok = true;
+            }
+        }
+    }
+    if (sd == 0) {
+        s_conf[la] = conf;
+        s_idx[la] = cand_ok ? i : 0x7fffffff;
+    }
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float c2 = s_conf[threadIdx.x + o];
+            const int i2 = s_idx[threadIdx.x + o];
+            if (c2 > s_conf[threadIdx.x] || (c2 == s_conf[threadIdx.x] && i2 < s_idx[threadIdx.x])) {
+                s_conf[threadIdx.x] = c2;
+                s_idx[threadIdx.x] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    float* mine = cand + ((long long)b * nblk + blockIdx.x) * 8;
+    if (s_conf[0] < 0.f) {
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(mine + 4, -1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((int*)mine + 5, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (sd == 0 && cand_ok && i == s_idx[0]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) __hip_atomic_store(mine + k, r[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 4, conf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((int*)mine + 5, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the candidate is written through before the arrival is counted
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(counter + b, 1) == nblk - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < 64) {
+        float bc = -1.f;
+        int bi = 0x7fffffff, bk = -1;
+        for (int k = threadIdx.x; k < nblk; k += 64) {
+            const float c2 = __hip_atomic_load(cand + ((long long)b * nblk + k) * 8 + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int i2 = __hip_atomic_load((const int*)(cand + ((long long)b * nblk + k) * 8) + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c2 > bc || (c2 == bc && i2 < bi)) {
+                bc = c2;
+                bi = i2;
+                bk = k;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float c2 = __shfl_down(bc, o, 64);
+            const int i2 = __shfl_down(bi, o, 64), k2 = __shfl_down(bk, o, 64);
+            if (c2 > bc || (c2 == bc && i2 < bi)) {
+                bc = c2;
+                bi = i2;
+                bk = k2;
+            }
+        }
+        if (threadIdx.x == 0) {
+            float* o = a.best + (long long)b * 5;
+            if (bc < 0.f) {
+                o[0] = o[1] = o[2] = o[3] = 0.f;
+                o[4] = -1.f;
+            } else {
+                const float* w = cand + ((long long)b * nblk + bk) * 8;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = __hip_atomic_load(w + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                o[4] = bc;
+            }
+            counter[b] = 0;   // ready for the next launch on this stream
+        }
     }
 }
 

@@ -75,6 +75,10 @@ class YoloV8Detector:
             raise
         self._h = h
 
+    def set_option(self, name: str, value: int) -> None:
+        """Tuning knobs of the C-ABI (``og_yolo_set_option``): ``latency_batch``, ``splitk_slots``, ``splitk_div``."""
+        check(lib().og_yolo_set_option(self._h, name.encode(), int(value)), f"og_yolo_set_option({name})")
+
     def detect_batch(self, frames_bgr: np.ndarray, conf: float = 0.25, want_pred: bool = False):
         """``[B,H,W,3]`` u8 BGR at network size (sides multiples of 32) → ``best [B,5]`` (+ ``pred [B,A,5]``)."""
         f = np.ascontiguousarray(frames_bgr, dtype=np.uint8)

@@ -214,17 +214,28 @@ def test_batched_and_per_frame_detector_paths_agree_on_any_frame_size(det, shape
     H, W = shape
     fr = frames(6, H, W, seed=H + W)
     best = d.detect_frames(fr, 0.25)
-    td = og.TemporalDetector(d, conf=0.25)
-    per_frame = [td.detect(f) for f in fr]
-    td2 = og.TemporalDetector(lambda f, c: None)
-    batched = [td2.update(b[None, :4], b[4:5], W, H) if b[4] >= 0 else td2.update(None, None, W, H) for b in best]
-    assert per_frame == batched
-    for i, f in enumerate(fr):                      # raw boxes too, bit for bit (same letterbox, same scale-back)
+    d.set_option("latency_batch", 0)                # one-frame calls on the batched kernels: bit for bit
+    try:
+        td = og.TemporalDetector(d, conf=0.25)
+        per_frame = [td.detect(f) for f in fr]
+        td2 = og.TemporalDetector(lambda f, c: None)
+        batched = [td2.update(b[None, :4], b[4:5], W, H) if b[4] >= 0 else td2.update(None, None, W, H) for b in best]
+        assert per_frame == batched
+        for i, f in enumerate(fr):                      # raw boxes too, bit for bit (same letterbox, same scale-back)
+            xy, cf = d(f, 0.25)
+            assert (len(cf) == 0) == (best[i, 4] < 0)
+            if len(cf):
+                assert np.array_equal(xy[0], best[i, :4]) and cf[0] == best[i, 4]
+                assert 0 <= xy[0, 0] <= xy[0, 2] <= W and 0 <= xy[0, 1] <= xy[0, 3] <= H
+    finally:
+        d.set_option("latency_batch", 1)
+    # default: one-frame calls take the latency path (K split over workgroups -> float sums in another order):
+    # the same boxes to rounding (<= 1e-3 px at the frame's scale, conf <= 1e-5)
+    for i, f in enumerate(fr):
         xy, cf = d(f, 0.25)
         assert (len(cf) == 0) == (best[i, 4] < 0)
         if len(cf):
-            assert np.array_equal(xy[0], best[i, :4]) and cf[0] == best[i, 4]
-            assert 0 <= xy[0, 0] <= xy[0, 2] <= W and 0 <= xy[0, 1] <= xy[0, 3] <= H
+            assert np.abs(xy[0] - best[i, :4]).max() <= 1e-3 * max(1.0, max(H, W) / 256) and abs(cf[0] - best[i, 4]) <= 1e-5
     # the two callers: gated area waveform and the eval harness give what the per-frame loop gives
     feats = (4, 8, 16, 32)
     m = og.UNet(1, 1, feats)
@@ -244,3 +255,53 @@ def test_batched_and_per_frame_detector_paths_agree_on_any_frame_size(det, shape
         t = og.TemporalDetector(d)
         stateless.append(t.detect(f))
     assert agg["yolo+unet"]["n_det"] == sum(b is not None for b in stateless)
+
+
+NAMES = ["model.0", "model.1", "model.2", "model.3", "model.4", "model.5", "model.6", "model.7", "model.8", "model.9",
+         "model.12", "model.15", "model.16", "model.18", "model.19", "model.21", "box0", "cls0", "box1", "cls1", "box2", "cls2"]
+
+
+@pytest.mark.parametrize("shape,nb,latency_batch", [((256, 256), 1, 1), ((96, 160), 1, 1), ((320, 256), 1, 1), ((32, 32), 1, 1),
+                                                     ((256, 256), 3, 4), ((512, 512), 1, 1)])
+def test_latency_path_matches_oracle_and_batched_path(det, shape, nb, latency_batch):
+    """One-frame calls (detector.py:58's pattern) take their own path: K split over workgroups with a fused reduce on every
+    small conv, 32-column tiles, the Detect level's two branches as one chain (block-diagonal weights), one-launch SPPF
+    pools, a multi-workgroup decode.  Every module output against the oracle at the batched path's tolerance, and the
+    candidates / best box against the batched kernels on the same frames (they differ only in float summation order)."""
+    import torch
+    from oracle import yolo_oracle as Y
+    sd, d = det
+    H, W = shape
+    fr = frames(nb, H, W, seed=H * 3 + W + nb)
+    try:
+        d.set_option("latency_batch", 0)
+        best0, pred0 = d.detect_batch(fr, conf=0.25, want_pred=True)
+        d.set_option("latency_batch", latency_batch)
+        best1, pred1 = d.detect_batch(fr, conf=0.25, want_pred=True)
+        with torch.no_grad():
+            _, taps = Y.forward(sd, Y.preprocess_bgr(fr))
+        for n in NAMES:
+            ref = taps[n].numpy()
+            got = d.activation(n, nb)
+            assert got.shape == ref.shape, (n, got.shape, ref.shape)
+            err = np.abs(got - ref).max()
+            assert err <= 2e-4 * max(1.0, np.abs(ref).max()), (n, err)
+    finally:
+        d.set_option("latency_batch", 1)
+    assert np.abs(pred1[..., :4] - pred0[..., :4]).max() <= 1e-3 * max(1.0, max(H, W) / 256)
+    assert np.abs(pred1[..., 4] - pred0[..., 4]).max() <= 1e-5
+    for b in range(nb):
+        i = int(np.argmax(pred1[b, :, 4]))
+        if pred1[b, i, 4] > 0.25:
+            assert np.array_equal(best1[b], pred1[b, i])      # multi-workgroup arg-max == arg-max of its own candidates
+        else:
+            assert best1[b, 4] == -1
+        assert abs(best1[b, 4] - best0[b, 4]) <= 1e-5
+
+
+def test_latency_path_option_validation(det):
+    sd, d = det
+    for name, bad in (("latency_batch", 65), ("splitk_max", 0), ("splitk_min_steps", 2), ("nonsense", 1)):
+        with pytest.raises(Exception):
+            d.set_option(name, bad)
+    d.set_option("latency_batch", 1)
