@@ -47,6 +47,7 @@ struct ConvLayer {  // one 3x3 conv + BN + ReLU, or one 2x2 transposed conv
     int NT = 1;
     float* d_w = nullptr;
     float* d_w_h = nullptr;   // the same weights as f16 hi/lo pairs in the H layout (opt-in split precision)
+    float* d_w1 = nullptr;    // 3x3 convs with NT == 2: the same weights packed for 32-column tiles (split-K launches)
     float* d_scale = nullptr;
     float* d_shift = nullptr;
 };
@@ -109,6 +110,7 @@ struct og_unet {
     int xcd_group = 1;   // see LaunchCtx::xcd_group
     int splitk_occ = 1;  // split-K parts on the occupancy kernel (0: persistent kernel)
     int splitk_min_steps = 9;  // smallest K part of a split 3x3 conv, in (chunk, tap) steps (9 = one channel chunk)
+    int splitk_nt1 = 1;  // split 3x3 launches on 32-column tiles (twice the workgroups, half the MFMAs per K part)
     int splitk_slots = 1, splitk_div = 2;  // occupancy split-K: target workgroups per CU; split when the launch fills < 1/div of them
                                            // (round-2 sweep, one to three lanes, both precisions: 1 / 2 beats round 1's 2 / 4 at 1-4 frames per launch)
     int occ_min_pct = 100; // occupancy kernel when workgroups >= pct % of the CU count (0: one full round of 2-3 per CU);
@@ -284,6 +286,7 @@ int build_conv(og_unet* h, ConvLayer& L, const std::string& wkey, const std::str
     int rc;
     if ((rc = upload(pk, &L.d_w))) return rc;
     if ((rc = upload(pack_gemm_b_h(L.Cout_p, L.Cin_p, 9, L.NT, at), &L.d_w_h))) return rc;
+    if (L.NT == 2 && (rc = upload(pack_gemm_b(L.Cout_p, L.Cin_p, 9, 1, at), &L.d_w1))) return rc;
     if ((rc = upload(sc, &L.d_scale))) return rc;
     if ((rc = upload(sh, &L.d_shift))) return rc;
     return OG_OK;
@@ -328,9 +331,10 @@ std::vector<int> ident_map(int Cin) {
 void free_layer(ConvLayer& L) {
     if (L.d_w) (void)hipFree(L.d_w);
     if (L.d_w_h) (void)hipFree(L.d_w_h);
+    if (L.d_w1) (void)hipFree(L.d_w1);
     if (L.d_scale) (void)hipFree(L.d_scale);
     if (L.d_shift) (void)hipFree(L.d_shift);
-    L.d_w = L.d_w_h = L.d_scale = L.d_shift = nullptr;
+    L.d_w = L.d_w_h = L.d_w1 = L.d_scale = L.d_shift = nullptr;
 }
 
 void drop_graphs(og_unet* h) {
@@ -704,14 +708,23 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         return rc_h;
     }
     int impl = h->conv_impl;
+    int NTu = L.NT;   // column sub-tiles per workgroup of THIS launch (32-column tiles on split 3x3 launches, see splitk_nt1)
     if (impl == 1 || impl == 2) {
+        const bool sk_occ = (impl == 2 && h->splitk_occ);
         const int nt = (L.mode == 0) ? L.Cout_p / (32 * L.NT) : 4 * L.Cout_p / 64;
         const int tiles8 = B * a.tiles_x * ((in.H + 7) / 8);
-        const bool sk_occ = (impl == 2 && h->splitk_occ);
         // occupancy split-K of a 3x3 conv: parts are ranges of (chunk, tap) steps, at least splitk_min_steps each
         const int k_units = (sk_occ && L.mode == 0) ? (a.n_chunks * 9) / h->splitk_min_steps : a.n_chunks;
-        const int ks = pick_ksplit(tiles8 * nt, k_units, h->n_cu * (sk_occ ? h->splitk_slots : h->wg_per_cu), (L.NT == 2) ? 2 : 1,
-                                   h->splitk != 0 && h->d_partial != nullptr, sk_occ ? h->splitk_div : 4);
+        int ks = pick_ksplit(tiles8 * nt, k_units, h->n_cu * (sk_occ ? h->splitk_slots : h->wg_per_cu), (L.NT == 2) ? 2 : 1,
+                             h->splitk != 0 && h->d_partial != nullptr, sk_occ ? h->splitk_div : 4);
+        bool nt1 = false;   // 32-column tiles where they still leave room to split K
+        if (ks > 1 && sk_occ && h->splitk_nt1 && L.mode == 0 && L.NT == 2 && L.d_w1 != nullptr) {
+            const int ks1 = pick_ksplit(tiles8 * nt * 2, k_units, h->n_cu * h->splitk_slots, 1, true, h->splitk_div);
+            if (ks1 > 1) {
+                ks = ks1;
+                nt1 = true;
+            }
+        }
         // The occupancy variant needs at least one full round of workgroups (2/CU on 16x16 tiles, 3/CU on
         // 8x16); below that the persistent kernel (2/CU, balanced static schedule, split-K when the launch
         // cannot even fill a quarter of the chip) is faster.
@@ -725,6 +738,10 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
             a.tiles_y = (in.H + 7) / 8;
             a.n_spatial = tiles8;
             a.ksplit = split ? ks : 1;
+            if (impl == 4 && nt1) {
+                NTu = 1;
+                a.wpk = L.d_w1;
+            }
         }
     }
     a.stamps = nullptr;
@@ -745,8 +762,8 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
             prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma_o<2,0,16>" : "k_conv_mfma_o<1,0,16>", fl);
             rc = (L.NT == 2) ? launch_conv_o<2, 0, 16, 2>(ctx, a, n_ntiles) : launch_conv_o<1, 0, 16, 2>(ctx, a, n_ntiles);
         } else if (impl == 4) {
-            prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma_o<2,0,8>+splitK" : "k_conv_mfma_o<1,0,8>+splitK", fl);
-            rc = (L.NT == 2) ? launch_conv_o<2, 0, TH, 3>(ctx, a, n_ntiles) : launch_conv_o<1, 0, TH, 3>(ctx, a, n_ntiles);
+            prof_begin(h, L.name, NTu == 2 ? "k_conv_mfma_o<2,0,8>+splitK" : "k_conv_mfma_o<1,0,8>+splitK", fl);
+            rc = (NTu == 2) ? launch_conv_o<2, 0, TH, 3>(ctx, a, n_ntiles) : launch_conv_o<1, 0, TH, 3>(ctx, a, L.Cout_p / 32);
         } else if (impl == 2 || impl == 3) {
             a.ksplit = 1;
             prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma_o<2,0,8>" : "k_conv_mfma_o<1,0,8>", fl);
@@ -1452,6 +1469,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "tps_nt2" && (value == 1 || value == 3)) slot = &h->tps_nt2;
     else if (n == "xcd_group" && (value == 0 || value == 1)) slot = &h->xcd_group;
     else if (n == "splitk_occ" && (value == 0 || value == 1)) slot = &h->splitk_occ;
+    else if (n == "splitk_nt1" && (value == 0 || value == 1)) slot = &h->splitk_nt1;
     else if (n == "splitk_fused" && (value == 0 || value == 1)) slot = &h->splitk_fused;
     else if (n == "splitk_slots" && value >= 1 && value <= 4) slot = &h->splitk_slots;
     else if (n == "splitk_min_steps" && value >= 1 && value <= 9) slot = &h->splitk_min_steps;
@@ -1572,6 +1590,7 @@ static int stream_impl(og_unet* h, const uint8_t* frames, int B, int H, int W, i
     auto& R = h->ring;
     const size_t HW = (size_t)H * W, fb = HW * ch;
     const bool pinned = is_pinned_host(frames);
+    const bool single = n_chunks == 1;
 
     auto retire = [&](og_unet::Slot& s) -> int {   // wait for the slot's outputs and hand them to the caller
         if (s.b0 < 0) return OG_OK;
@@ -1589,13 +1608,18 @@ static int stream_impl(og_unet* h, const uint8_t* frames, int B, int H, int W, i
             memcpy(s.h_in, src, nb * fb);
             src = s.h_in;
         }
-        HIPCHK(hipMemcpyAsync(s.d_in, src, nb * fb, hipMemcpyHostToDevice, R.s_h2d));
+        // a call that is ONE micro-batch has nothing to overlap: its copies go on the compute stream, in order, and the two
+        // cross-stream hand-overs (tens of microseconds each on a one-frame call) disappear
+        const hipStream_t s_in = single ? lane->stream : R.s_h2d, s_out = single ? lane->stream : R.s_d2h;
+        HIPCHK(hipMemcpyAsync(s.d_in, src, nb * fb, hipMemcpyHostToDevice, s_in));
         if (boxes) {
             memcpy(s.h_boxes, boxes + 4 * (size_t)b0, (size_t)nb * 16);
-            HIPCHK(hipMemcpyAsync(s.d_boxes, s.h_boxes, (size_t)nb * 16, hipMemcpyHostToDevice, R.s_h2d));
+            HIPCHK(hipMemcpyAsync(s.d_boxes, s.h_boxes, (size_t)nb * 16, hipMemcpyHostToDevice, s_in));
         }
-        HIPCHK(hipEventRecord(s.ev_h2d, R.s_h2d));
-        HIPCHK(hipStreamWaitEvent(lane->stream, s.ev_h2d, 0));
+        if (!single) {
+            HIPCHK(hipEventRecord(s.ev_h2d, R.s_h2d));
+            HIPCHK(hipStreamWaitEvent(lane->stream, s.ev_h2d, 0));
+        }
         const uint8_t* gray = s.d_in;
         if (ch == 3) {   // cv2.cvtColor(frm_bgr, COLOR_BGR2GRAY) of features.py:235, on the device, in front of the chain
             const long long n = (long long)nb * H * W;
@@ -1607,12 +1631,14 @@ static int stream_impl(og_unet* h, const uint8_t* frames, int B, int H, int W, i
         int rc2 = run_chunk(lane, KIND_U8, gray, nb, H, W, thr, boxes ? s.d_boxes : nullptr, mask ? s.d_mask : nullptr,
                             area ? s.d_area : nullptr, logits ? s.d_logits : nullptr);
         if (rc2) return rc2;
-        HIPCHK(hipEventRecord(s.ev_done, lane->stream));
-        HIPCHK(hipStreamWaitEvent(R.s_d2h, s.ev_done, 0));
-        if (area) HIPCHK(hipMemcpyAsync(s.h_area, s.d_area, (size_t)nb * 4, hipMemcpyDeviceToHost, R.s_d2h));
-        if (mask) HIPCHK(hipMemcpyAsync(s.h_mask, s.d_mask, nb * HW, hipMemcpyDeviceToHost, R.s_d2h));
-        if (logits) HIPCHK(hipMemcpyAsync(s.h_logits, s.d_logits, nb * HW * 4, hipMemcpyDeviceToHost, R.s_d2h));
-        HIPCHK(hipEventRecord(s.ev_out, R.s_d2h));
+        if (!single) {
+            HIPCHK(hipEventRecord(s.ev_done, lane->stream));
+            HIPCHK(hipStreamWaitEvent(R.s_d2h, s.ev_done, 0));
+        }
+        if (area) HIPCHK(hipMemcpyAsync(s.h_area, s.d_area, (size_t)nb * 4, hipMemcpyDeviceToHost, s_out));
+        if (mask) HIPCHK(hipMemcpyAsync(s.h_mask, s.d_mask, nb * HW, hipMemcpyDeviceToHost, s_out));
+        if (logits) HIPCHK(hipMemcpyAsync(s.h_logits, s.d_logits, nb * HW * 4, hipMemcpyDeviceToHost, s_out));
+        HIPCHK(hipEventRecord(s.ev_out, s_out));
         s.b0 = b0;
         s.nb = nb;
         return OG_OK;
