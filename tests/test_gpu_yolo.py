@@ -305,3 +305,24 @@ def test_latency_path_option_validation(det):
         with pytest.raises(Exception):
             d.set_option(name, bad)
     d.set_option("latency_batch", 1)
+
+
+def test_latency_path_interleaved_with_batched_calls_and_no_detection(det):
+    """One handle, one arena: one-frame calls (fused Detect chain: other buffers than the batched layout) between batched calls
+    give what they give on their own; a threshold nothing passes returns conf = -1 from the multi-workgroup decode too; the
+    device entry point takes the same path."""
+    import torch
+    sd, d = det
+    fr = frames(5, 256, 256, seed=77)
+    big = d.detect_batch(fr, 0.25)
+    one = [d.detect_batch(fr[i:i + 1], 0.25)[0] for i in range(5)]
+    for rep in range(2):
+        assert np.array_equal(d.detect_batch(fr, 0.25), big)
+        for i in (3, 0, 4):
+            assert np.array_equal(d.detect_batch(fr[i:i + 1], 0.25)[0], one[i])      # deterministic, whatever ran before
+    assert np.abs(np.stack(one)[:, :4] - big[:, :4]).max() <= 1e-3 and np.abs(np.stack(one)[:, 4] - big[:, 4]).max() <= 1e-5
+    none = d.detect_batch(fr[:1], 0.9999)
+    assert none[0, 4] == -1 and not none[0, :4].any()
+    dev = torch.from_numpy(fr).to("cuda:0")
+    for i in range(3):
+        assert np.array_equal(d.detect_dev(dev[i], 1, 256, 256, 0.25)[0], one[i])
