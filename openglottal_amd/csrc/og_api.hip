@@ -48,6 +48,7 @@ struct ConvLayer {  // one 3x3 conv + BN + ReLU, or one 2x2 transposed conv
     float* d_w = nullptr;
     float* d_w_h = nullptr;   // the same weights as f16 hi/lo pairs in the H layout (opt-in split precision)
     float* d_w1 = nullptr;    // 3x3 convs with NT == 2: the same weights packed for 32-column tiles (split-K launches)
+    float* d_ww = nullptr;    // 3x3 convs with NT == 2: Winograd F(2x2,3x3) image (pack_wino)
     float* d_scale = nullptr;
     float* d_shift = nullptr;
 };
@@ -110,6 +111,7 @@ struct og_unet {
     int xcd_group = 1;   // see LaunchCtx::xcd_group
     int splitk_occ = 1;  // split-K parts on the occupancy kernel (0: persistent kernel)
     int splitk_min_steps = 9;  // smallest K part of a split 3x3 conv, in (chunk, tap) steps (9 = one channel chunk)
+    int wino = 0;        // 64-column 3x3 layers in Winograd F(2x2,3x3) form (f32) where a launch fills the chip with 16x16 tiles
     int splitk_nt1 = 1;  // split 3x3 launches on 32-column tiles (twice the workgroups, half the MFMAs per K part)
     int splitk_slots = 1, splitk_div = 2;  // occupancy split-K: target workgroups per CU; split when the launch fills < 1/div of them
                                            // (round-2 sweep, one to three lanes, both precisions: 1 / 2 beats round 1's 2 / 4 at 1-4 frames per launch)
@@ -229,6 +231,33 @@ std::vector<float> pack_gemm_b(int Ncols_p, int Kp, int taps, int NT, F&& weight
     return out;
 }
 
+// Winograd F(2x2, 3x3) image of a 3x3 conv's weights for k_conv_wino: U = G g G^T (computed in double, rounded once),
+//   [n_tile of 64 columns][16-channel chunk][position 4i + j][column r in 0..64)[4 slots of 4 floats], slot' = slot ^ ((r>>2)&3)
+template <typename F>
+std::vector<float> pack_wino(int Ncols_p, int Kp, F&& weight_at /*(n, k, tap)->float*/) {
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int n_tiles = Ncols_p / 64, n_c16 = Kp / 16;
+    std::vector<float> out((size_t)Ncols_p * Kp * 16, 0.f);
+    for (int nt = 0; nt < n_tiles; ++nt)
+        for (int c = 0; c < n_c16; ++c)
+            for (int r = 0; r < 64; ++r)
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int sl = ps ^ ((r >> 2) & 3);
+                    for (int e = 0; e < 4; ++e) {
+                        double g[3][3], t[4][3];
+                        for (int tp = 0; tp < 9; ++tp) g[tp / 3][tp % 3] = (double)weight_at(nt * 64 + r, c * 16 + sl * 4 + e, tp);
+                        for (int i = 0; i < 4; ++i)
+                            for (int x = 0; x < 3; ++x) t[i][x] = G[i][0] * g[0][x] + G[i][1] * g[1][x] + G[i][2] * g[2][x];
+                        for (int i = 0; i < 4; ++i)
+                            for (int j = 0; j < 4; ++j) {
+                                const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+                                out[((((size_t)nt * n_c16 + c) * 16 + (4 * i + j)) * 64 + r) * 16 + ps * 4 + e] = (float)u;
+                            }
+                    }
+                }
+    return out;
+}
+
 // Split-precision image of the same weights (og_kernels.hpp "H layout"): per (row, chunk, tap) the 128 bytes hold eight
 // 16-byte slots, logical slot s < 4 = f16 hi of k = 32c + 8s .. +7, slot 4+s = f16 lo (scaled by 2^11) of the same k;
 // physical slot = logical ^ ((r>>1)&7) as in the f32 image.  Same byte size, so it is carried in a float vector.
@@ -287,6 +316,7 @@ int build_conv(og_unet* h, ConvLayer& L, const std::string& wkey, const std::str
     if ((rc = upload(pk, &L.d_w))) return rc;
     if ((rc = upload(pack_gemm_b_h(L.Cout_p, L.Cin_p, 9, L.NT, at), &L.d_w_h))) return rc;
     if (L.NT == 2 && (rc = upload(pack_gemm_b(L.Cout_p, L.Cin_p, 9, 1, at), &L.d_w1))) return rc;
+    if (L.NT == 2 && (rc = upload(pack_wino(L.Cout_p, L.Cin_p, at), &L.d_ww))) return rc;
     if ((rc = upload(sc, &L.d_scale))) return rc;
     if ((rc = upload(sh, &L.d_shift))) return rc;
     return OG_OK;
@@ -332,9 +362,10 @@ void free_layer(ConvLayer& L) {
     if (L.d_w) (void)hipFree(L.d_w);
     if (L.d_w_h) (void)hipFree(L.d_w_h);
     if (L.d_w1) (void)hipFree(L.d_w1);
+    if (L.d_ww) (void)hipFree(L.d_ww);
     if (L.d_scale) (void)hipFree(L.d_scale);
     if (L.d_shift) (void)hipFree(L.d_shift);
-    L.d_w = L.d_w_h = L.d_w1 = L.d_scale = L.d_shift = nullptr;
+    L.d_w = L.d_w_h = L.d_w1 = L.d_ww = L.d_scale = L.d_shift = nullptr;
 }
 
 void drop_graphs(og_unet* h) {
@@ -500,6 +531,31 @@ int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     return OG_OK;
 }
 
+constexpr int kWinoLds = 18 * 18 * 64 + 16 * 64 * 64 + 2 * 8 * 4096;
+
+int launch_conv_wino(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {   // 16x16 tiles, 64 columns, one workgroup per CU
+    ConvArgs a = a_in;
+    a.stamps = nullptr;
+    a.ksplit = 1;
+    a.tile_counter = nullptr;
+    const int frames = a.n_spatial / (a.tiles_x * a.tiles_y);
+    a.zdiv = n_ntiles;
+    a.frames = frames;
+    a.zgroup_shift = 0;
+    if (c.xcd_group && a.zdiv > 1) {
+        int txy = a.tiles_x * a.tiles_y, g = 8;
+        while (g > 1 && txy % 2 == 0) { txy /= 2; g /= 2; }
+        while (g > frames) g /= 2;
+        while ((1 << a.zgroup_shift) < g) ++a.zgroup_shift;
+    }
+    const int G = 1 << a.zgroup_shift, groups = (frames + G - 1) / G;
+    a.zrcp = 1.0f / (float)(a.zdiv * G);
+    if ((long long)groups * G * a.zdiv > 65535) return fail(OG_EINVAL, "micro-batch too large for one launch (grid.z): lower the chunk size");
+    hipLaunchKernelGGL(k_conv_wino, dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), kWinoLds, c.stream, a);
+    HIPCHK(hipGetLastError());
+    return OG_OK;
+}
+
 template <int NT, int MODE, int TH, int OCC, bool SQ = false>
 int launch_conv_h(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {   // split-precision twin of launch_conv_o (no split-K)
     constexpr int lds = conv_o_lds<NT, MODE, TH>();
@@ -574,6 +630,7 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 3, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 3, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 16>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 16>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoLds));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 1, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 1, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 8>()));
@@ -754,7 +811,14 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         const int n_ntiles = L.Cout_p / (32 * L.NT);
         if (out.H != in.H || out.W != in.W) return fail(OG_EINVAL, "conv shape mismatch");
         const double fl = 2.0 * px * 9.0 * L.Cin * L.Cout;
-        if (impl == 0) {
+        if (h->wino && L.NT == 2 && L.d_ww != nullptr && full16 && a.head_w == nullptr && a.ksplit == 1 &&
+            B * (in.H / 16) * (in.W / 16) * n_ntiles >= h->n_cu) {
+            a.tiles_y = in.H / 16;
+            a.n_spatial = B * a.tiles_x * a.tiles_y;
+            a.wpk = L.d_ww;
+            prof_begin(h, L.name, "k_conv_wino", fl);
+            rc = launch_conv_wino(ctx, a, n_ntiles);
+        } else if (impl == 0) {
             prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma<2,0,8>" : "k_conv_mfma<1,0,8>", fl);
             rc = (L.NT == 2) ? launch_conv_t<2, 0, TH>(h, a, n_ntiles) : launch_conv_t<1, 0, TH>(h, a, n_ntiles);
         } else if (impl == 2 && big) {
@@ -1470,6 +1534,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "xcd_group" && (value == 0 || value == 1)) slot = &h->xcd_group;
     else if (n == "splitk_occ" && (value == 0 || value == 1)) slot = &h->splitk_occ;
     else if (n == "splitk_nt1" && (value == 0 || value == 1)) slot = &h->splitk_nt1;
+    else if (n == "wino" && (value == 0 || value == 1)) slot = &h->wino;
     else if (n == "splitk_fused" && (value == 0 || value == 1)) slot = &h->splitk_fused;
     else if (n == "splitk_slots" && value >= 1 && value <= 4) slot = &h->splitk_slots;
     else if (n == "splitk_min_steps" && value >= 1 && value <= 9) slot = &h->splitk_min_steps;

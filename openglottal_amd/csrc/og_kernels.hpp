@@ -1056,6 +1056,227 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     }
 }
 
+// Winograd F(2x2, 3x3) form of the 3x3 conv for the 64-column layers, all arithmetic in f32: per 2x2 output window the
+// 4x4 input patch d becomes V = B^T d B (adds only), the 16 entries of V meet the pre-transformed weights U = G g G^T in 16
+// independent GEMMs over the input channels (MFMA), and the window's outputs are Y = A^T M A (adds only): 16 multiplies per
+// window and channel pair instead of 36 -- 2.25x fewer MFMAs than the direct form for the same result to f32 rounding
+// (the transforms re-associate the sums; same fixtures, same tolerance as every other variant).
+//   tile     16x16 output pixels = 64 windows (GEMM rows) x 64 output channels; wave (wm, wn) = 32 windows x 32 channels x
+//            all 16 positions = 256 accumulator registers -> ONE workgroup per CU, one wave per SIMD
+//   LDS      raw 18x18-pixel halo of a 16-channel chunk (20 KB, LDS-DMA) | V [16 positions][64 windows][16 ch] (64 KB) |
+//            U ring: 2 groups of 8 positions x [64 cout][16 ch] (2 x 32 KB, LDS-DMA)
+//   per chunk  each thread transforms one (window, 4-channel) item: 16 x ds_read_b128 -> 32 vector adds -> 16 x
+//            ds_write_b128, its reads taken under the MFMAs of the chunk before; 128 MFMAs per wave
+//   epilogue the output transform runs in registers (a lane's 16 positions of one accumulator slot are one window) and
+//            hands conv_epilogue_b the direct kernel's accumulator layout: window (m = r & 3, 2 (r >> 2) + lh) of a wave
+__global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
+    constexpr int RAW_BYTES = 18 * 18 * 64;
+    constexpr int V_BYTES = 16 * 64 * 64;
+    constexpr int UG_BYTES = 8 * 4096;
+    constexpr int RAW_PIECES = 18 * 18 * 4;
+    constexpr int RAW_IT = (RAW_PIECES + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // tile decode: as k_conv_mfma_o (grid.z = frame group x column tile x frame-in-group)
+    const int bz = (int)blockIdx.z;
+    const int gz = a.zdiv << a.zgroup_shift;
+    const int q_ = (gz == 1) ? bz : (int)(((float)bz + 0.5f) * a.zrcp);
+    const int rz = bz - q_ * gz;
+    const int n_tile = rz >> a.zgroup_shift;
+    const int b = (q_ << a.zgroup_shift) + (rz & ((1 << a.zgroup_shift) - 1));
+    if (b >= a.frames) return;
+    const int ty0 = (int)blockIdx.y * 16, tx0 = (int)blockIdx.x * 16;
+
+    const og_i32x4 in_rsrc = og_make_rsrc(a.in + (long long)b * a.in_frame_stride + a.in_ch_off,
+                                          (unsigned)(a.in_frame_stride - a.in_ch_off) * 4u);
+    // raw halo image: pixel (hy, hx) at index hy * 18 + (hx & 1) * 9 + (hx >> 1) (even and odd columns apart: the windows of
+    // a row then read consecutive 64-B pixels), 4 pieces of 16 B per pixel
+    unsigned hoff[RAW_IT];
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) {
+        const int id = it * 256 + tid;
+        const int p = id >> 2, pc = id & 3;
+        const int hy = p / 18, r = p - hy * 18;
+        const int hx = (r >= 9) ? 2 * (r - 9) + 1 : 2 * r;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        const bool inb = id < RAW_PIECES && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        hoff[it] = inb ? (unsigned)((gy * a.W + gx) * a.in_pix_stride * 4 + pc * 16) : OG_OOB;
+    }
+    const bool last_valid = ((RAW_IT - 1) * 256 + tid) < RAW_PIECES;
+    const unsigned lds0 = og_lds_addr(smem);
+    auto stage_raw = [&](int c16) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+#pragma unroll
+        for (int it = 0; it < RAW_IT; ++it)
+            if (it < RAW_IT - 1 || last_valid) glds16b(hoff[it], in_rsrc, (unsigned)c16 * 64u, base + it * 4096);
+    };
+    const int n_c16 = a.n_chunks * 2;
+    const og_i32x4 w_rsrc = og_make_rsrc(a.wpk + (long long)n_tile * n_c16 * (16 * 1024), (unsigned)n_c16 * 65536u);
+    auto stage_u = [&](int stage, int grp) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + RAW_BYTES + V_BYTES + stage * UG_BYTES + wave * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) glds16b((unsigned)tid * 16u, w_rsrc, (unsigned)grp * UG_BYTES + i * 4096, base + i * 4096);
+    };
+    stage_raw(0);
+    stage_u(0, 0);
+
+    // fragment addressing.  MFMA row i of a wave = window (row 4 wm + (i & 3), column 2 (i >> 3) + ((i >> 2) & 1)); 16-B slot
+    // s of a window's / an output channel's 64-B row sits at s ^ (bits that differ between rows 256 B apart): conflict-free
+    const int wa = (4 * wm + (li & 3)) * 8 + 2 * (li >> 3) + ((li >> 2) & 1);
+    const int nb = wn * 32 + li;
+    unsigned abase[2], bbase[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        abase[j] = lds0 + RAW_BYTES + wa * 64 + (((2 * j + lh) ^ (li & 3)) << 4);
+        bbase[j] = lds0 + RAW_BYTES + V_BYTES + nb * 64 + (((2 * j + lh) ^ ((nb >> 2) & 3)) << 4);
+        asm volatile("" : "+v"(abase[j]));
+        asm volatile("" : "+v"(bbase[j]));
+    }
+    // transform role: window wt (row wt >> 3, column wt & 7), channels 4 qc .. 4 qc + 3 of the chunk
+    const int wt = tid >> 2, qc = tid & 3;
+    unsigned rbase = lds0 + (unsigned)((2 * (wt >> 3) * 18 + (wt & 7)) * 64 + qc * 16);
+    unsigned vwbase = lds0 + RAW_BYTES + (unsigned)(wt * 64 + ((qc ^ ((wt >> 3) & 3)) << 4));
+    asm volatile("" : "+v"(rbase));
+    asm volatile("" : "+v"(vwbase));
+
+    const int ecol = n_tile * 64 + wn * 32 + li;
+    const float esc = a.scale[ecol], esh = a.shift[ecol];
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    // One wave per SIMD: nothing but this wave's own instruction stream can fill the matrix pipe's shadow, so everything that
+    // is not an MFMA is cut into micro-ops and issued between the four MFMAs of a step (64 cycles each), in a fixed order:
+    //   group g = 0 of chunk c (positions 0-7):  the hi half of V (positions 8-15) of chunk c from the registers `tv`; LDS-DMA of
+    //                                            the next U group and of the raw halo of chunk c + 1
+    //   group g = 1 (positions 8-15):            LDS-DMA of the next U group; raw halo of chunk c + 1 -> registers -> B^T d B ->
+    //                                            `tv`; its lo half (positions 0-7) into V
+    // Two barriers per chunk (one per group): every LDS region is written in the group after its last reader's group.
+    f32x4 d[16], t[16], tv[16];
+    auto raw_read = [&](int n) {   // pixel (2 wy + i, 2 wx + j) of the halo: index (2 wy + i) * 18 + (j & 1) * 9 + wx + (j >> 1)
+        const int i = n >> 2, j = n & 3;
+        d[n] = og_lds_read16(rbase + (unsigned)((i * 18 + (j & 1) * 9 + (j >> 1)) * 64));
+    };
+    auto row_op = [&](int n) {   // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first (n = 4 * row + j)
+        const int r = n >> 2, j = n & 3;
+        t[n] = (r == 0) ? d[0 + j] - d[8 + j] : (r == 1) ? d[4 + j] + d[8 + j] : (r == 2) ? d[8 + j] - d[4 + j] : d[4 + j] - d[12 + j];
+    };
+    auto col_op = [&](int n) {   // then columns (n = 4 * i + column)
+        const int i = n >> 2, cc = n & 3;
+        tv[n] = (cc == 0) ? t[4 * i + 0] - t[4 * i + 2] : (cc == 1) ? t[4 * i + 1] + t[4 * i + 2] : (cc == 2) ? t[4 * i + 2] - t[4 * i + 1]
+                                                                                                           : t[4 * i + 1] - t[4 * i + 3];
+    };
+    auto v_write = [&](int k) { *(OG_LDS_AS f32x4*)(unsigned long long)(vwbase + (unsigned)(k * 4096)) = tv[k]; };
+    auto u_piece = [&](int stage, int grp, int i) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + RAW_BYTES + V_BYTES + stage * UG_BYTES + wave * 1024);
+        glds16b((unsigned)tid * 16u, w_rsrc, (unsigned)grp * UG_BYTES + i * 4096, base + i * 4096);
+    };
+    auto raw_piece = [&](int c16, int it) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+        if (it < RAW_IT - 1 || last_valid) glds16b(hoff[it], in_rsrc, (unsigned)c16 * 64u, base + it * 4096);
+    };
+
+    og_wait_dma();
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 16; ++n) raw_read(n);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) row_op(n);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) col_op(n);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v_write(k);
+    __syncthreads();   // lo half of V (chunk 0) complete; every read of the raw buffer done
+
+    for (int c = 0; c < n_c16; ++c) {
+        const bool nxt = c + 1 < n_c16;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int grp = 2 * c + g;
+            const bool more_u = grp + 1 < 2 * n_c16;
+            f32x4 fa[2], fb[2];
+            fa[0] = og_lds_read16(abase[0] + (unsigned)(8 * g * 4096));
+            fb[0] = og_lds_read16(bbase[0] + (unsigned)(g * UG_BYTES));
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const int k = 8 * g + (st >> 1);
+                const f32x4 av = fa[st & 1], bv = fb[st & 1];
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[k], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 1 < 16) {   // slot 0: the fragments of the next step
+                    const int kn = (st + 1) >> 1, jn = (st + 1) & 1;
+                    fa[(st + 1) & 1] = og_lds_read16(abase[jn] + (unsigned)((8 * g + kn) * 4096));
+                    fb[(st + 1) & 1] = og_lds_read16(bbase[jn] + (unsigned)(g * UG_BYTES + kn * 4096));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[k], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // slot 1
+                if (g == 0) {
+                    if (st < 8) v_write(8 + st);                              // hi half of this chunk's V
+                } else if (nxt) {
+                    if (st < 2) { for (int n = 0; n < 4; ++n) raw_read(8 * st + n); }
+                    else if (st >= 3 && st < 7) { row_op(4 * (st - 3)); row_op(4 * (st - 3) + 1); }
+                    else if (st >= 7 && st < 11) { col_op(4 * (st - 7)); col_op(4 * (st - 7) + 1); }
+                    else if (st >= 11 && st < 15) v_write(2 * (st - 11));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[k], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // slot 2
+                if (g == 0) {
+                    if (st < 8 && more_u) u_piece(1, grp + 1, st);
+                } else {
+                    if (st < 8 && more_u) u_piece(0, grp + 1, st);
+                    if (nxt) {
+                        if (st < 2) { for (int n = 4; n < 8; ++n) raw_read(8 * st + n); }
+                        else if (st >= 3 && st < 7) { row_op(4 * (st - 3) + 2); row_op(4 * (st - 3) + 3); }
+                        else if (st >= 7 && st < 11) { col_op(4 * (st - 7) + 2); col_op(4 * (st - 7) + 3); }
+                        else if (st >= 11 && st < 15) v_write(2 * (st - 11) + 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[k], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // slot 3
+                if (g == 0 && nxt && st < RAW_IT) raw_piece(c + 1, st);   // early in the group: waited at its end
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            og_wait_dma();
+            __syncthreads();
+        }
+    }
+
+    // ---- output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1], in registers; then the shared epilogue ----
+    f32x16 o[4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float tm[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tm[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
+            tm[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+        }
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            o[r & 3][4 * (r >> 2) + 2 * y + 0] = tm[y][0] + tm[y][1] + tm[y][2];
+            o[r & 3][4 * (r >> 2) + 2 * y + 1] = tm[y][1] - tm[y][2] - tm[y][3];
+        }
+    }
+    unsigned char* const scr = smem + wave * 5120;   // the raw buffer is dead (20 KB = 4 x 5 KB)
+    if (a.act == 1) conv_epilogue_b<2, 0, 16, 1, false>(a, o, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+    else conv_epilogue_b<2, 0, 16, 0, false>(a, o, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+}
+
 // Split-precision twin of k_conv_mfma_o (MODE 0: 3x3 conv, MODE 1: 2x2 stride-2 transposed conv): same tiles, halo /
 // weight staging, LDS images, swizzles and fragment addressing; the operands are f16 hi/lo pairs in the H layout and each
 // (chunk, tap) costs 6 x v_mfma_f32_32x32x16_f16 per 32-row sub-tile instead of 16 x v_mfma_f32_32x32x2_f32.  No split-K.
