@@ -111,7 +111,8 @@ struct og_unet {
     int xcd_group = 1;   // see LaunchCtx::xcd_group
     int splitk_occ = 1;  // split-K parts on the occupancy kernel (0: persistent kernel)
     int splitk_min_steps = 9;  // smallest K part of a split 3x3 conv, in (chunk, tap) steps (9 = one channel chunk)
-    int wino = 0;        // 64-column 3x3 layers in Winograd F(2x2,3x3) form (f32) where a launch fills the chip with 16x16 tiles
+    int wino = 1;        // 64-column 3x3 layers in Winograd F(2x2,3x3) form (k_conv_wino, all f32) -- decided once per kernel chain
+    bool wino_chain = false;   // (run_chunk): when the chain's deepest such layer fills the chip with one 16x16 tile per CU
     int splitk_nt1 = 1;  // split 3x3 launches on 32-column tiles (twice the workgroups, half the MFMAs per K part)
     int splitk_slots = 1, splitk_div = 2;  // occupancy split-K: target workgroups per CU; split when the launch fills < 1/div of them
                                            // (round-2 sweep, one to three lanes, both precisions: 1 / 2 beats round 1's 2 / 4 at 1-4 frames per launch)
@@ -811,8 +812,7 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         const int n_ntiles = L.Cout_p / (32 * L.NT);
         if (out.H != in.H || out.W != in.W) return fail(OG_EINVAL, "conv shape mismatch");
         const double fl = 2.0 * px * 9.0 * L.Cin * L.Cout;
-        if (h->wino && L.NT == 2 && L.d_ww != nullptr && full16 && a.head_w == nullptr && a.ksplit == 1 &&
-            B * (in.H / 16) * (in.W / 16) * n_ntiles >= h->n_cu) {
+        if (h->wino_chain && L.NT == 2 && L.d_ww != nullptr && full16 && a.head_w == nullptr && a.ksplit == 1) {
             a.tiles_y = in.H / 16;
             a.n_spatial = B * a.tiles_x * a.tiles_y;
             a.wpk = L.d_ww;
@@ -1057,10 +1057,19 @@ int enqueue_head(og_unet* h, int B, int H, int W, float thr, const int32_t* boxe
 
 // One chunk of B (<= capB) frames.  Body eager, or replayed from a cached hipGraph
 // (launch-bound at small B otherwise: 5*L+2 launches, MI355X_MICROARCH.md "graph-replay-floor").
+// Winograd form for the whole chain or for none of it: the deepest map decides (it has the fewest tiles), so that results do
+// not change from layer to layer with the micro-batch size -- every micro-batch that fills the chip takes it.
+void pick_chain_form(og_unet* h, int B, int H, int W) {
+    const int Hd = H >> h->L, Wd = W >> h->L;
+    const long long deep_tiles = (long long)B * ((Hd + 15) / 16) * ((Wd + 15) / 16) * (cp32(2 * h->features[h->L - 1]) / 64);
+    h->wino_chain = h->wino && h->precision == 0 && h->conv_impl == 2 && deep_tiles >= h->n_cu;
+}
+
 int run_chunk(og_unet* h, int kind, const void* in, int B, int H, int W, float thr, const int32_t* boxes, uint8_t* mask,
               int32_t* area, float* logits) {
     h->lastB = B;
     int rc;
+    pick_chain_form(h, B, H, W);
     const bool ff = can_fuse_first(h, kind, B, H, W);
     const bool fuse = can_fuse_head(h);
     if (ff) {
@@ -1076,7 +1085,7 @@ int run_chunk(og_unet* h, int kind, const void* in, int B, int H, int W, float t
         key.B = B;
         key.H = H;
         key.W = W;
-        key.flags = (fuse ? 1 : 0) | (ff ? 2 : 0) | (h->precision ? 4 : 0);
+        key.flags = (fuse ? 1 : 0) | (ff ? 2 : 0) | (h->precision ? 4 : 0) | (h->wino_chain ? 8 : 0);
         key.capB = h->capB;
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
@@ -2007,6 +2016,7 @@ int og_unet_profile(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, in
         h->prof = &tr;
         HIPCHK(hipMemsetAsync(h->stage, 0, (size_t)B * 4, h->stream));
         const bool ff = can_fuse_first(h, KIND_U8, B, H, W);
+        pick_chain_form(h, B, H, W);
         rc = ff ? enqueue_first_fused(h, gray_dev, B, H, W) : enqueue_first(h, KIND_U8, gray_dev, B, H, W);
         const bool fuse = can_fuse_head(h);
         if (!rc) rc = enqueue_body(h, B, fuse, ff);

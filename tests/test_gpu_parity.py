@@ -487,6 +487,12 @@ def test_occupancy_kernels_on_partial_tiles_large_batch():
     scale2 = max(1.0, np.abs(ref_logits2).max())
     assert np.abs(logits2[:4] - ref_logits2).max() <= TOL * scale2
     assert np.all(np.abs(ref_logits2[(masks2[:4] > 0) != (ref_mask2 > 0)]) <= TOL * scale2)
+    # (that batch filled the chip: its 64-column layers ran in Winograd form, padded channel slots and all.)  The direct
+    # occupancy kernels at the same batch against the persistent kernels at batch 2: bit for bit
+    m2.set_option("wino", 0)
+    _, areas2, logits2d = m2.segment(fr2, want_logits=True)
+    assert np.abs(logits2d[:4] - ref_logits2).max() <= TOL * scale2 and np.abs(logits2d - logits2).max() <= TOL * scale2
+    logits2 = logits2d
     m2.set_chunk(2)
     m2.set_option("splitk", 0)
     _, areas2b, logits2b = m2.segment(fr2[:6], want_logits=True)
