@@ -48,7 +48,7 @@ struct ConvLayer {  // one 3x3 conv + BN + ReLU, or one 2x2 transposed conv
     float* d_w = nullptr;
     float* d_w_h = nullptr;   // the same weights as f16 hi/lo pairs in the H layout (opt-in split precision)
     float* d_w1 = nullptr;    // 3x3 convs with NT == 2: the same weights packed for 32-column tiles (split-K launches)
-    float* d_ww = nullptr;    // 3x3 convs with NT == 2: Winograd F(2x2,3x3) image (pack_wino)
+    float* d_ww = nullptr;    // 3x3 convs: Winograd F(2x2,3x3) image for k_conv_wino<NT> (pack_wino)
     float* d_scale = nullptr;
     float* d_shift = nullptr;
 };
@@ -112,6 +112,7 @@ struct og_unet {
     int splitk_occ = 1;  // split-K parts on the occupancy kernel (0: persistent kernel)
     int splitk_min_steps = 9;  // smallest K part of a split 3x3 conv, in (chunk, tap) steps (9 = one channel chunk)
     int wino = 1;        // 64-column 3x3 layers in Winograd F(2x2,3x3) form (k_conv_wino, all f32) -- decided once per kernel chain
+    int wino_first = 1;  // Winograd chains: first layer unfused so that the second conv takes k_conv_wino<1>
     bool wino_chain = false;   // (run_chunk): when the chain's deepest such layer fills the chip with one 16x16 tile per CU
     int splitk_nt1 = 1;  // split 3x3 launches on 32-column tiles (twice the workgroups, half the MFMAs per K part)
     int splitk_slots = 1, splitk_div = 2;  // occupancy split-K: target workgroups per CU; split when the launch fills < 1/div of them
@@ -232,27 +233,29 @@ std::vector<float> pack_gemm_b(int Ncols_p, int Kp, int taps, int NT, F&& weight
     return out;
 }
 
-// Winograd F(2x2, 3x3) image of a 3x3 conv's weights for k_conv_wino: U = G g G^T (computed in double, rounded once),
-//   [n_tile of 64 columns][16-channel chunk][position 4i + j][column r in 0..64)[4 slots of 4 floats], slot' = slot ^ ((r>>2)&3)
+// Winograd F(2x2, 3x3) image of a 3x3 conv's weights for k_conv_wino<NT>: U = G g G^T (computed in double, rounded once),
+//   [n_tile of 32 NT columns][chunk of KC = 8 NT channels][position 4i + j][column r][KC / 4 slots of 4 floats],
+//   slot' = slot ^ ((r>>2)&3) (NT 2) | slot ^ ((r>>3)&1) (NT 1)
 template <typename F>
-std::vector<float> pack_wino(int Ncols_p, int Kp, F&& weight_at /*(n, k, tap)->float*/) {
+std::vector<float> pack_wino(int Ncols_p, int Kp, int NT, F&& weight_at /*(n, k, tap)->float*/) {
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-    const int n_tiles = Ncols_p / 64, n_c16 = Kp / 16;
+    const int rows = 32 * NT, KC = 8 * NT, SL = KC / 4;
+    const int n_tiles = Ncols_p / rows, n_ck = Kp / KC;
     std::vector<float> out((size_t)Ncols_p * Kp * 16, 0.f);
     for (int nt = 0; nt < n_tiles; ++nt)
-        for (int c = 0; c < n_c16; ++c)
-            for (int r = 0; r < 64; ++r)
-                for (int ps = 0; ps < 4; ++ps) {
-                    const int sl = ps ^ ((r >> 2) & 3);
+        for (int c = 0; c < n_ck; ++c)
+            for (int r = 0; r < rows; ++r)
+                for (int ps = 0; ps < SL; ++ps) {
+                    const int sl = (NT == 2) ? ps ^ ((r >> 2) & 3) : ps ^ ((r >> 3) & 1);
                     for (int e = 0; e < 4; ++e) {
                         double g[3][3], t[4][3];
-                        for (int tp = 0; tp < 9; ++tp) g[tp / 3][tp % 3] = (double)weight_at(nt * 64 + r, c * 16 + sl * 4 + e, tp);
+                        for (int tp = 0; tp < 9; ++tp) g[tp / 3][tp % 3] = (double)weight_at(nt * rows + r, c * KC + sl * 4 + e, tp);
                         for (int i = 0; i < 4; ++i)
                             for (int x = 0; x < 3; ++x) t[i][x] = G[i][0] * g[0][x] + G[i][1] * g[1][x] + G[i][2] * g[2][x];
                         for (int i = 0; i < 4; ++i)
                             for (int j = 0; j < 4; ++j) {
                                 const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
-                                out[((((size_t)nt * n_c16 + c) * 16 + (4 * i + j)) * 64 + r) * 16 + ps * 4 + e] = (float)u;
+                                out[((((size_t)nt * n_ck + c) * 16 + (4 * i + j)) * rows + r) * KC + ps * 4 + e] = (float)u;
                             }
                     }
                 }
@@ -317,7 +320,7 @@ int build_conv(og_unet* h, ConvLayer& L, const std::string& wkey, const std::str
     if ((rc = upload(pk, &L.d_w))) return rc;
     if ((rc = upload(pack_gemm_b_h(L.Cout_p, L.Cin_p, 9, L.NT, at), &L.d_w_h))) return rc;
     if (L.NT == 2 && (rc = upload(pack_gemm_b(L.Cout_p, L.Cin_p, 9, 1, at), &L.d_w1))) return rc;
-    if (L.NT == 2 && (rc = upload(pack_wino(L.Cout_p, L.Cin_p, at), &L.d_ww))) return rc;
+    if ((rc = upload(pack_wino(L.Cout_p, L.Cin_p, L.NT, at), &L.d_ww))) return rc;
     if ((rc = upload(sc, &L.d_scale))) return rc;
     if ((rc = upload(sh, &L.d_shift))) return rc;
     return OG_OK;
@@ -532,9 +535,11 @@ int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     return OG_OK;
 }
 
-constexpr int kWinoLds = 18 * 18 * 64 + 16 * 64 * 64 + 2 * 8 * 4096;
+template <int NT>
+constexpr int wino_lds() { return (32 / NT + 2) * (NT == 2 ? 18 : 19) * (32 * NT) + 16 * 4096 + 2 * 8 * (32 * NT) * (32 * NT); }
 
-int launch_conv_wino(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {   // 16x16 tiles, 64 columns, one workgroup per CU
+template <int NT>
+int launch_conv_wino(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {   // 16x16 (NT 2) / 32x16 (NT 1) pixel tiles, one workgroup per CU
     ConvArgs a = a_in;
     a.stamps = nullptr;
     a.ksplit = 1;
@@ -552,7 +557,7 @@ int launch_conv_wino(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {  
     const int G = 1 << a.zgroup_shift, groups = (frames + G - 1) / G;
     a.zrcp = 1.0f / (float)(a.zdiv * G);
     if ((long long)groups * G * a.zdiv > 65535) return fail(OG_EINVAL, "micro-batch too large for one launch (grid.z): lower the chunk size");
-    hipLaunchKernelGGL(k_conv_wino, dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), kWinoLds, c.stream, a);
+    hipLaunchKernelGGL(k_conv_wino<NT>, dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), wino_lds<NT>(), c.stream, a);
     HIPCHK(hipGetLastError());
     return OG_OK;
 }
@@ -631,7 +636,8 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 3, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 3, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 16>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 16>()));
-    HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoLds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino<2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds<2>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds<1>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 1, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 1, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 8>()));
@@ -812,12 +818,12 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         const int n_ntiles = L.Cout_p / (32 * L.NT);
         if (out.H != in.H || out.W != in.W) return fail(OG_EINVAL, "conv shape mismatch");
         const double fl = 2.0 * px * 9.0 * L.Cin * L.Cout;
-        if (h->wino_chain && L.NT == 2 && L.d_ww != nullptr && full16 && a.head_w == nullptr && a.ksplit == 1) {
-            a.tiles_y = in.H / 16;
+        if (h->wino_chain && L.d_ww != nullptr && full16 && (L.NT == 2 || in.H % 32 == 0) && (a.head_w == nullptr || L.NT == 1) && a.ksplit == 1) {
+            a.tiles_y = in.H / (32 / L.NT);
             a.n_spatial = B * a.tiles_x * a.tiles_y;
             a.wpk = L.d_ww;
-            prof_begin(h, L.name, "k_conv_wino", fl);
-            rc = launch_conv_wino(ctx, a, n_ntiles);
+            prof_begin(h, L.name, L.NT == 2 ? "k_conv_wino<2>" : "k_conv_wino<1>", fl);
+            rc = (L.NT == 2) ? launch_conv_wino<2>(ctx, a, n_ntiles) : launch_conv_wino<1>(ctx, a, n_ntiles);
         } else if (impl == 0) {
             prof_begin(h, L.name, L.NT == 2 ? "k_conv_mfma<2,0,8>" : "k_conv_mfma<1,0,8>", fl);
             rc = (L.NT == 2) ? launch_conv_t<2, 0, TH>(h, a, n_ntiles) : launch_conv_t<1, 0, TH>(h, a, n_ntiles);
@@ -929,6 +935,8 @@ int enqueue_first(og_unet* h, int kind, const void* in, int B, int H, int W) {
 // and nobody asking for the "downs.0.a" tap.
 bool can_fuse_first(const og_unet* h, int kind, int B, int H, int W) {
     if (!h->fuse_first || kind != KIND_U8 || h->conv_impl != 2 || h->keep_taps || cp32(h->features[0]) != 32) return false;
+    // Winograd chain: the second conv runs as k_conv_wino<1> on the first layer's stored output (less work than the fusion saves)
+    if (h->wino_chain && h->wino_first && H % 32 == 0 && W % 16 == 0) return false;
     const int items = B * ((W + 15) / 16) * ((H + 7) / 8);
     return items >= 3 * h->n_cu;
 }
@@ -1012,7 +1020,9 @@ int enqueue_body(og_unet* h, int B, bool skip_last = false, bool skip_first = fa
 int enqueue_last_with_head(og_unet* h, int B, float thr, const int32_t* boxes, uint8_t* mask, int32_t* area, float* logits) {
     const int L = h->L;
     const Act& u = h->UA[0];
-    const int tiles = ((u.W + 15) / 16) * ((u.H + 7) / 8);   // the fused launch always runs on 8x16 tiles (NT == 1)
+    // count slots per frame: the fused launch runs on 8x16 tiles (direct kernel) or on 32x16 tiles (k_conv_wino<1>)
+    const bool wino_last = h->wino_chain && h->dec_b[L - 1].d_ww != nullptr && u.H % 32 == 0 && u.W % 16 == 0;
+    const int tiles = wino_last ? (u.W / 16) * (u.H / 32) : ((u.W + 15) / 16) * ((u.H + 7) / 8);
     const size_t need = (size_t)B * tiles * 4;
     if (area && need > h->counts_cap) {
         if (h->d_counts) {
@@ -1544,6 +1554,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "splitk_occ" && (value == 0 || value == 1)) slot = &h->splitk_occ;
     else if (n == "splitk_nt1" && (value == 0 || value == 1)) slot = &h->splitk_nt1;
     else if (n == "wino" && (value == 0 || value == 1)) slot = &h->wino;
+    else if (n == "wino_first" && (value == 0 || value == 1)) slot = &h->wino_first;
     else if (n == "splitk_fused" && (value == 0 || value == 1)) slot = &h->splitk_fused;
     else if (n == "splitk_slots" && value >= 1 && value <= 4) slot = &h->splitk_slots;
     else if (n == "splitk_min_steps" && value >= 1 && value <= 9) slot = &h->splitk_min_steps;
@@ -2015,8 +2026,8 @@ int og_unet_profile(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, in
         std::vector<og_unet::ProfEntry> tr;
         h->prof = &tr;
         HIPCHK(hipMemsetAsync(h->stage, 0, (size_t)B * 4, h->stream));
-        const bool ff = can_fuse_first(h, KIND_U8, B, H, W);
         pick_chain_form(h, B, H, W);
+        const bool ff = can_fuse_first(h, KIND_U8, B, H, W);
         rc = ff ? enqueue_first_fused(h, gray_dev, B, H, W) : enqueue_first(h, KIND_U8, gray_dev, B, H, W);
         const bool fuse = can_fuse_head(h);
         if (!rc) rc = enqueue_body(h, B, fuse, ff);

@@ -1069,18 +1069,33 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
 //            ds_write_b128, its reads taken under the MFMAs of the chunk before; 128 MFMAs per wave
 //   epilogue the output transform runs in registers (a lane's 16 positions of one accumulator slot are one window) and
 //            hands conv_epilogue_b the direct kernel's accumulator layout: window (m = r & 3, 2 (r >> 2) + lh) of a wave
+// NT = 1 (the 32-column layers): the same kernel on a 32x16-pixel tile = 128 windows x 32 channels, wave wm = 32 windows x all
+//   16 positions, 8-channel chunks (V stays 64 KB: [16][128 windows][8 ch]); one K step per position instead of two, so the
+//   same side work is issued in half the MFMA steps.
+template <int NT>
 __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
-    constexpr int RAW_BYTES = 18 * 18 * 64;
-    constexpr int V_BYTES = 16 * 64 * 64;
-    constexpr int UG_BYTES = 8 * 4096;
-    constexpr int RAW_PIECES = 18 * 18 * 4;
-    constexpr int RAW_IT = (RAW_PIECES + 255) / 256;
+    constexpr int KC = 8 * NT;                    // input channels per chunk
+    constexpr int PB = KC * 4;                    // bytes of one pixel's / window's / output channel's chunk row: 64 | 32
+    constexpr int SL = KC / 4;                    // 16-B slots per row: 4 | 2
+    constexpr int KS = KC / 8;                    // K steps (of 8 channels = 4 MFMAs) per position: 2 | 1
+    constexpr int TH = 32 / NT;                   // tile height in pixels: 16 | 32 (width 16)
+    constexpr int RP = (NT == 2) ? 18 : 19;       // pixels per raw row (NT 1: one unused slot, so that the transform's reads of
+                                                  // window rows 0..3 of a wave start in four different 64-B bank groups)
+    constexpr int RAW_PIX = (TH + 2) * RP;
+    constexpr int RAW_BYTES = RAW_PIX * PB;       // 20736 | 19584
+    constexpr int V_BYTES = 16 * 4096;            // [16 positions][64 | 128 windows][PB]
+    constexpr int UP_BYTES = 32 * NT * PB;        // one position's weights: [32 NT cout][PB] = 4096 | 1024
+    constexpr int UG_BYTES = 8 * UP_BYTES;        // ring slot: 8 positions
+    constexpr int U_IT = UG_BYTES / 4096;         // LDS-DMA instructions per wave and ring slot: 8 | 2
+    constexpr int RAW_PIECES = RAW_PIX * SL;
+    constexpr int RAW_IT = (RAW_PIECES + 255) / 256;   // 6 | 5
+    constexpr int NST = 8 * KS;                   // MFMA steps per group: 16 | 8
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 1, wm = wave >> 1;
+    const int wn = (NT == 2) ? (wave & 1) : 0, wm = (NT == 2) ? (wave >> 1) : wave;
     const int li = lane & 31, lh = lane >> 5;
 
     // tile decode: as k_conv_mfma_o (grid.z = frame group x column tile x frame-in-group)
@@ -1091,61 +1106,72 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
     const int n_tile = rz >> a.zgroup_shift;
     const int b = (q_ << a.zgroup_shift) + (rz & ((1 << a.zgroup_shift) - 1));
     if (b >= a.frames) return;
-    const int ty0 = (int)blockIdx.y * 16, tx0 = (int)blockIdx.x * 16;
+    const int ty0 = (int)blockIdx.y * TH, tx0 = (int)blockIdx.x * 16;
 
     const og_i32x4 in_rsrc = og_make_rsrc(a.in + (long long)b * a.in_frame_stride + a.in_ch_off,
                                           (unsigned)(a.in_frame_stride - a.in_ch_off) * 4u);
-    // raw halo image: pixel (hy, hx) at index hy * 18 + (hx & 1) * 9 + (hx >> 1) (even and odd columns apart: the windows of
-    // a row then read consecutive 64-B pixels), 4 pieces of 16 B per pixel
+    // raw halo image: pixel (hy, hx) at index hy * RP + (hx & 1) * 9 + (hx >> 1) (even and odd columns apart: the windows of
+    // a row then read consecutive pixels), SL pieces of 16 B per pixel
     unsigned hoff[RAW_IT];
 #pragma unroll
     for (int it = 0; it < RAW_IT; ++it) {
         const int id = it * 256 + tid;
-        const int p = id >> 2, pc = id & 3;
-        const int hy = p / 18, r = p - hy * 18;
+        const int p = id / SL, pc = id % SL;   // the DMA lands piece id at byte 16 id: with RP = 19 the unused slot of every row is a
+        const int hy = p / RP, r = p - hy * RP;  // piece like any other (r == 18: fetched out of bounds = zeros, never read)
         const int hx = (r >= 9) ? 2 * (r - 9) + 1 : 2 * r;
         const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-        const bool inb = id < RAW_PIECES && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        const bool inb = id < RAW_PIECES && r < 18 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
         hoff[it] = inb ? (unsigned)((gy * a.W + gx) * a.in_pix_stride * 4 + pc * 16) : OG_OOB;
     }
     const bool last_valid = ((RAW_IT - 1) * 256 + tid) < RAW_PIECES;
     const unsigned lds0 = og_lds_addr(smem);
-    auto stage_raw = [&](int c16) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
-#pragma unroll
-        for (int it = 0; it < RAW_IT; ++it)
-            if (it < RAW_IT - 1 || last_valid) glds16b(hoff[it], in_rsrc, (unsigned)c16 * 64u, base + it * 4096);
-    };
-    const int n_c16 = a.n_chunks * 2;
-    const og_i32x4 w_rsrc = og_make_rsrc(a.wpk + (long long)n_tile * n_c16 * (16 * 1024), (unsigned)n_c16 * 65536u);
-    auto stage_u = [&](int stage, int grp) {
+    const int n_ck = a.n_chunks * (32 / KC);
+    const og_i32x4 w_rsrc = og_make_rsrc(a.wpk + (long long)n_tile * n_ck * (16 * UP_BYTES / 4), (unsigned)n_ck * (16u * UP_BYTES));
+    auto u_piece = [&](int stage, int grp, int i) {
         const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + RAW_BYTES + V_BYTES + stage * UG_BYTES + wave * 1024);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) glds16b((unsigned)tid * 16u, w_rsrc, (unsigned)grp * UG_BYTES + i * 4096, base + i * 4096);
+        glds16b((unsigned)tid * 16u, w_rsrc, (unsigned)grp * UG_BYTES + i * 4096, base + i * 4096);
     };
-    stage_raw(0);
-    stage_u(0, 0);
-
-    // fragment addressing.  MFMA row i of a wave = window (row 4 wm + (i & 3), column 2 (i >> 3) + ((i >> 2) & 1)); 16-B slot
-    // s of a window's / an output channel's 64-B row sits at s ^ (bits that differ between rows 256 B apart): conflict-free
-    const int wa = (4 * wm + (li & 3)) * 8 + 2 * (li >> 3) + ((li >> 2) & 1);
-    const int nb = wn * 32 + li;
-    unsigned abase[2], bbase[2];
+    auto raw_piece = [&](int ck, int it) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+        if (it < RAW_IT - 1 || last_valid) glds16b(hoff[it], in_rsrc, (unsigned)ck * PB, base + it * 4096);
+    };
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        abase[j] = lds0 + RAW_BYTES + wa * 64 + (((2 * j + lh) ^ (li & 3)) << 4);
-        bbase[j] = lds0 + RAW_BYTES + V_BYTES + nb * 64 + (((2 * j + lh) ^ ((nb >> 2) & 3)) << 4);
+    for (int it = 0; it < RAW_IT; ++it) raw_piece(0, it);
+#pragma unroll
+    for (int i = 0; i < U_IT; ++i) u_piece(0, 0, i);
+
+    // Fragment addressing.  MFMA row i of a wave = window (row 4 wm + (i & 3), column wx = 2 (i >> 3) + ((i >> 2) & 1)).
+    // NT 2: window w's 64-B row at w * 64, slot s at s ^ (w >> 3 & 3): the 16 lanes of a read hit 16 distinct 16-B bank groups.
+    // NT 1: 32-B rows, so the window ORDER carries half of the spreading: row index 8 (4 wm + (wx >> 1)) + (i & 3) + 4 (wx & 1),
+    //       slot s at s ^ (wx >> 1 & 1).  Weights: output channel n's row, slot s at s ^ (n >> 2 & 3) | s ^ (n >> 3 & 1).
+    const int wxa = 2 * (li >> 3) + ((li >> 2) & 1);
+    const int nb = wn * 32 + li;
+    unsigned abase[KS], bbase[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+        if (NT == 2) {
+            abase[j] = lds0 + RAW_BYTES + ((4 * wm + (li & 3)) * 8 + wxa) * 64 + (((2 * j + lh) ^ (li & 3)) << 4);
+            bbase[j] = lds0 + RAW_BYTES + V_BYTES + nb * 64 + (((2 * j + lh) ^ ((nb >> 2) & 3)) << 4);
+        } else {
+            abase[j] = lds0 + RAW_BYTES + (8 * (4 * wm + (wxa >> 1)) + (li & 3) + 4 * (wxa & 1)) * 32 + ((lh ^ ((wxa >> 1) & 1)) << 4);
+            bbase[j] = lds0 + RAW_BYTES + V_BYTES + nb * 32 + ((lh ^ ((nb >> 3) & 1)) << 4);
+        }
         asm volatile("" : "+v"(abase[j]));
         asm volatile("" : "+v"(bbase[j]));
     }
-    // transform role: window wt (row wt >> 3, column wt & 7), channels 4 qc .. 4 qc + 3 of the chunk
-    const int wt = tid >> 2, qc = tid & 3;
-    unsigned rbase = lds0 + (unsigned)((2 * (wt >> 3) * 18 + (wt & 7)) * 64 + qc * 16);
-    unsigned vwbase = lds0 + RAW_BYTES + (unsigned)(wt * 64 + ((qc ^ ((wt >> 3) & 3)) << 4));
+    // transform role: window (row wr, column wc), channels 4 qc .. 4 qc + 3 of the chunk
+    // (NT 1: lane bits = quad, column bit 0, row bits 1:0, column bits 2:1, so that the 16 lanes of a V write cover 16 bank groups)
+    const int qc = tid % SL;
+    const int wr = (NT == 2) ? (tid >> 5) : 4 * (tid >> 6) + ((tid >> 2) & 3);
+    const int wc = (NT == 2) ? ((tid >> 2) & 7) : ((tid >> 1) & 1) + 2 * ((tid >> 4) & 3);
+    const int wt = 8 * wr + wc;
+    unsigned rbase = lds0 + (unsigned)((2 * wr * RP + wc) * PB + qc * 16);
+    unsigned vwbase = (NT == 2) ? lds0 + RAW_BYTES + (unsigned)(wt * 64 + ((qc ^ (wr & 3)) << 4))
+                                : lds0 + RAW_BYTES + (unsigned)((8 * (4 * (wr >> 2) + (wc >> 1)) + (wr & 3) + 4 * (wc & 1)) * 32 + ((qc ^ ((wc >> 1) & 1)) << 4));
     asm volatile("" : "+v"(rbase));
     asm volatile("" : "+v"(vwbase));
 
-    const int ecol = n_tile * 64 + wn * 32 + li;
+    const int ecol = n_tile * 32 * NT + wn * 32 + li;
     const float esc = a.scale[ecol], esh = a.shift[ecol];
 
     f32x16 acc[16];
@@ -1162,9 +1188,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
     //                                            `tv`; its lo half (positions 0-7) into V
     // Two barriers per chunk (one per group): every LDS region is written in the group after its last reader's group.
     f32x4 d[16], t[16], tv[16];
-    auto raw_read = [&](int n) {   // pixel (2 wy + i, 2 wx + j) of the halo: index (2 wy + i) * 18 + (j & 1) * 9 + wx + (j >> 1)
+    auto raw_read = [&](int n) {   // pixel (2 wr + i, 2 wc + j) of the halo: index (2 wr + i) * RP + (j & 1) * 9 + wc + (j >> 1)
         const int i = n >> 2, j = n & 3;
-        d[n] = og_lds_read16(rbase + (unsigned)((i * 18 + (j & 1) * 9 + (j >> 1)) * 64));
+        d[n] = og_lds_read16(rbase + (unsigned)((i * RP + (j & 1) * 9 + (j >> 1)) * PB));
     };
     auto row_op = [&](int n) {   // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first (n = 4 * row + j)
         const int r = n >> 2, j = n & 3;
@@ -1176,72 +1202,79 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
                                                                                                            : t[4 * i + 1] - t[4 * i + 3];
     };
     auto v_write = [&](int k) { *(OG_LDS_AS f32x4*)(unsigned long long)(vwbase + (unsigned)(k * 4096)) = tv[k]; };
-    auto u_piece = [&](int stage, int grp, int i) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + RAW_BYTES + V_BYTES + stage * UG_BYTES + wave * 1024);
-        glds16b((unsigned)tid * 16u, w_rsrc, (unsigned)grp * UG_BYTES + i * 4096, base + i * 4096);
+    // micro-op n of the transform pipeline of a group-1 (32 raw reads are 16: reads 0-15, row ops 16-31, column ops 32-47, lo writes 48-55)
+    auto xf_op = [&](int n) {
+        if (n < 16) raw_read(n);
+        else if (n < 32) row_op(n - 16);
+        else if (n < 48) col_op(n - 32);
+        else if (n < 56) v_write(n - 48);
     };
-    auto raw_piece = [&](int c16, int it) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
-        if (it < RAW_IT - 1 || last_valid) glds16b(hoff[it], in_rsrc, (unsigned)c16 * 64u, base + it * 4096);
-    };
+    auto xf4 = [&](int n) { xf_op(n); xf_op(n + 1); xf_op(n + 2); xf_op(n + 3); };
 
     og_wait_dma();
     __syncthreads();
 #pragma unroll
-    for (int n = 0; n < 16; ++n) raw_read(n);
-#pragma unroll
-    for (int n = 0; n < 16; ++n) row_op(n);
-#pragma unroll
-    for (int n = 0; n < 16; ++n) col_op(n);
+    for (int n = 0; n < 48; ++n) xf_op(n);
 #pragma unroll
     for (int k = 0; k < 8; ++k) v_write(k);
     __syncthreads();   // lo half of V (chunk 0) complete; every read of the raw buffer done
 
-    for (int c = 0; c < n_c16; ++c) {
-        const bool nxt = c + 1 < n_c16;
+    for (int c = 0; c < n_ck; ++c) {
+        const bool nxt = c + 1 < n_ck;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const int grp = 2 * c + g;
-            const bool more_u = grp + 1 < 2 * n_c16;
+            const bool more_u = grp + 1 < 2 * n_ck;
             f32x4 fa[2], fb[2];
             fa[0] = og_lds_read16(abase[0] + (unsigned)(8 * g * 4096));
             fb[0] = og_lds_read16(bbase[0] + (unsigned)(g * UG_BYTES));
 #pragma unroll
-            for (int st = 0; st < 16; ++st) {
-                const int k = 8 * g + (st >> 1);
+            for (int st = 0; st < NST; ++st) {
+                const int k = 8 * g + st / KS;
                 const f32x4 av = fa[st & 1], bv = fb[st & 1];
                 acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[k], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (st + 1 < 16) {   // slot 0: the fragments of the next step
-                    const int kn = (st + 1) >> 1, jn = (st + 1) & 1;
+                if (st + 1 < NST) {   // slot 0: the fragments of the next step
+                    const int kn = (st + 1) / KS, jn = (st + 1) % KS;
                     fa[(st + 1) & 1] = og_lds_read16(abase[jn] + (unsigned)((8 * g + kn) * 4096));
-                    fb[(st + 1) & 1] = og_lds_read16(bbase[jn] + (unsigned)(g * UG_BYTES + kn * 4096));
+                    fb[(st + 1) & 1] = og_lds_read16(bbase[jn] + (unsigned)(g * UG_BYTES + kn * UP_BYTES));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[k], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 // slot 1
                 if (g == 0) {
-                    if (st < 8) v_write(8 + st);                              // hi half of this chunk's V
+                    if (NT == 2) { if (st < 8) v_write(8 + st); }                 // hi half of this chunk's V
+                    else v_write(8 + st);
                 } else if (nxt) {
-                    if (st < 2) { for (int n = 0; n < 4; ++n) raw_read(8 * st + n); }
-                    else if (st >= 3 && st < 7) { row_op(4 * (st - 3)); row_op(4 * (st - 3) + 1); }
-                    else if (st >= 7 && st < 11) { col_op(4 * (st - 7)); col_op(4 * (st - 7) + 1); }
-                    else if (st >= 11 && st < 15) v_write(2 * (st - 11));
+                    if (NT == 2) {   // reads in steps 0-1, row ops 3-6, column ops 7-10, lo writes 11-14
+                        if (st < 2) xf4(8 * st);
+                        else if (st >= 3 && st < 7) { xf_op(16 + 4 * (st - 3)); xf_op(16 + 4 * (st - 3) + 1); }
+                        else if (st >= 7 && st < 11) { xf_op(32 + 4 * (st - 7)); xf_op(32 + 4 * (st - 7) + 1); }
+                        else if (st >= 11 && st < 15) xf_op(48 + 2 * (st - 11));
+                    } else {         // reads in steps 0-1, row ops 2-3, column ops 4-5, lo writes 6-7
+                        if (st < 2) xf4(8 * st);
+                        else if (st < 4) xf4(16 + 8 * (st - 2));
+                        else if (st < 6) xf4(32 + 8 * (st - 4));
+                        else { xf_op(48 + 4 * (st - 6)); xf_op(48 + 4 * (st - 6) + 1); }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[k], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 // slot 2
-                if (g == 0) {
-                    if (st < 8 && more_u) u_piece(1, grp + 1, st);
-                } else {
-                    if (st < 8 && more_u) u_piece(0, grp + 1, st);
-                    if (nxt) {
-                        if (st < 2) { for (int n = 4; n < 8; ++n) raw_read(8 * st + n); }
-                        else if (st >= 3 && st < 7) { row_op(4 * (st - 3) + 2); row_op(4 * (st - 3) + 3); }
-                        else if (st >= 7 && st < 11) { col_op(4 * (st - 7) + 2); col_op(4 * (st - 7) + 3); }
-                        else if (st >= 11 && st < 15) v_write(2 * (st - 11) + 1);
+                if (st < U_IT && more_u) u_piece(g ^ 1, grp + 1, st);
+                if (g == 1 && nxt) {
+                    if (NT == 2) {
+                        if (st < 2) xf4(8 * st + 4);
+                        else if (st >= 3 && st < 7) { xf_op(16 + 4 * (st - 3) + 2); xf_op(16 + 4 * (st - 3) + 3); }
+                        else if (st >= 7 && st < 11) { xf_op(32 + 4 * (st - 7) + 2); xf_op(32 + 4 * (st - 7) + 3); }
+                        else if (st >= 11 && st < 15) xf_op(48 + 2 * (st - 11) + 1);
+                    } else {
+                        if (st < 2) xf4(8 * st + 4);
+                        else if (st < 4) xf4(16 + 8 * (st - 2) + 4);
+                        else if (st < 6) xf4(32 + 8 * (st - 4) + 4);
+                        else { xf_op(48 + 4 * (st - 6) + 2); xf_op(48 + 4 * (st - 6) + 3); }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1272,9 +1305,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
             o[r & 3][4 * (r >> 2) + 2 * y + 1] = tm[y][1] - tm[y][2] - tm[y][3];
         }
     }
-    unsigned char* const scr = smem + wave * 5120;   // the raw buffer is dead (20 KB = 4 x 5 KB)
-    if (a.act == 1) conv_epilogue_b<2, 0, 16, 1, false>(a, o, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
-    else conv_epilogue_b<2, 0, 16, 0, false>(a, o, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+    unsigned char* const scr = smem + wave * 5120;   // the raw buffer is dead (>= 19 KB; the epilogue's scratch runs into V, dead too)
+    if (a.act == 1) conv_epilogue_b<NT, 0, TH, 1, false>(a, o, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+    else conv_epilogue_b<NT, 0, TH, 0, false>(a, o, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
 }
 
 // Split-precision twin of k_conv_mfma_o (MODE 0: 3x3 conv, MODE 1: 2x2 stride-2 transposed conv): same tiles, halo /

@@ -2,7 +2,7 @@
 
 128 full-width (32,64,128,256) frames — the 80-frame structured GIRAFE stand-in (C1) + 48 frames of the seeded
 throughput stream (C2) — run exactly as `bench.py` runs them: device-resident u8 frames, 64 frames per kernel chain,
-two lanes, hipGraph replay, fused first layer and fused head, the 64-column 3x3 layers in Winograd F(2x2,3x3) form
+two lanes, hipGraph replay, fused head, every 3x3 layer behind the first in Winograd F(2x2,3x3) form
 (all f32; `wino` 0 = the direct kernels, checked against the same fixture).  Masks, areas, sampled logits and Dice vs GT are checked
 against tests/golden/unet_full128.npz, which tests/golden/gen_golden.py captured from the reference's own
 `unet_segment_frame` (openglottal/utils.py:218-241) and metric definitions (scripts/eval_girafe.py:113-124).
@@ -22,7 +22,7 @@ from openglottal_amd import synth
 pytestmark = pytest.mark.gpu
 
 TOL = 5e-5
-DOMINANT = "k_conv_wino"
+DOMINANT = "k_conv_wino<2>"
 DOMINANT_DIRECT = "k_conv_mfma_o<2,0,16>"
 
 
@@ -87,13 +87,12 @@ def test_bench_configuration_against_reference_fixture(setup):
     m.segment_dev(fdev, 128, 256, 256, area2)
     m.sync()
     assert torch.equal(area, area2)
-    # the chain really is the bench's: fused first layer, the Winograd kernel on the fourteen 64-column 3x3 layers, fused head
+    # the chain really is the bench's: the Winograd kernel on the fourteen 64-column and the three 32-column 3x3 layers, fused head
     prof = m.profile(fdev, 64, 256, 256, reps=1)
     kernels = [p["kernel"] for p in prof]
-    assert kernels.count(DOMINANT) == 14, kernels
-    assert kernels[0] == "k_conv_mfma_o<1,0,8,FIRST>", kernels
-    assert "k_head" not in kernels and "k_conv_first<u8>" not in kernels, kernels
-    assert all(k.startswith(("k_conv_mfma_o", "k_conv_wino")) for k in kernels), kernels
+    assert kernels.count(DOMINANT) == 14 and kernels.count("k_conv_wino<1>") == 3, kernels   # + the three 32-column layers
+    assert kernels[0] == "k_conv_first<u8>" and "k_head" not in kernels, kernels                # first layer unfused, head fused
+    assert all(k.startswith(("k_conv_mfma_o<2,1", "k_conv_wino", "k_conv_first")) for k in kernels), kernels
     # the direct form of the same chain (option "wino" 0: what every launch that does not fill the chip takes) against the
     # same fixture, and the two forms against each other: different roundings of the same f32 sums
     lg_w = logits.cpu().numpy()
@@ -106,6 +105,7 @@ def test_bench_configuration_against_reference_fixture(setup):
         print(f"direct form: flipped pixels {flips_d} of {128 * 65536}")
         kernels = [p["kernel"] for p in m.profile(fdev, 64, 256, 256, reps=1)]
         assert kernels.count(DOMINANT_DIRECT) == 10 and all(k.startswith("k_conv_mfma_o") for k in kernels), kernels
+        assert kernels[0] == "k_conv_mfma_o<1,0,8,FIRST>", kernels
     finally:
         m.set_option("wino", 1)
     assert np.abs(lg_w - logits.cpu().numpy()).max() <= TOL
