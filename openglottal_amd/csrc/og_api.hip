@@ -536,7 +536,7 @@ int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
 }
 
 template <int NT>
-constexpr int wino_lds() { return (32 / NT + 2) * (NT == 2 ? 18 : 19) * (32 * NT) + 16 * 4096 + 2 * 8 * (32 * NT) * (32 * NT); }
+constexpr int wino_lds() { return (32 / NT + 2) * 18 * (32 * NT) + 16 * 4096 + 2 * 8 * (32 * NT) * (32 * NT); }
 
 template <int NT>
 int launch_conv_wino(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {   // 16x16 (NT 2) / 32x16 (NT 1) pixel tiles, one workgroup per CU

@@ -1079,8 +1079,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
     constexpr int SL = KC / 4;                    // 16-B slots per row: 4 | 2
     constexpr int KS = KC / 8;                    // K steps (of 8 channels = 4 MFMAs) per position: 2 | 1
     constexpr int TH = 32 / NT;                   // tile height in pixels: 16 | 32 (width 16)
-    constexpr int RP = (NT == 2) ? 18 : 19;       // pixels per raw row (NT 1: one unused slot, so that the transform's reads of
-                                                  // window rows 0..3 of a wave start in four different 64-B bank groups)
+    constexpr int RP = 18;                        // pixels per raw row
     constexpr int RAW_PIX = (TH + 2) * RP;
     constexpr int RAW_BYTES = RAW_PIX * PB;       // 20736 | 19584
     constexpr int V_BYTES = 16 * 4096;            // [16 positions][64 | 128 windows][PB]
@@ -1116,8 +1115,8 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
 #pragma unroll
     for (int it = 0; it < RAW_IT; ++it) {
         const int id = it * 256 + tid;
-        const int p = id / SL, pc = id % SL;   // the DMA lands piece id at byte 16 id: with RP = 19 the unused slot of every row is a
-        const int hy = p / RP, r = p - hy * RP;  // piece like any other (r == 18: fetched out of bounds = zeros, never read)
+        const int p = id / SL, pc = id % SL;
+        const int hy = p / RP, r = p - hy * RP;
         const int hx = (r >= 9) ? 2 * (r - 9) + 1 : 2 * r;
         const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
         const bool inb = id < RAW_PIECES && r < 18 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
