@@ -159,7 +159,12 @@ int og_unet_set_graphs(og_unet* h, int enable);
  * threshold + area inside the last conv's epilogue), "keep_taps" 0|1, "precision" 0|1 (NOT bit-identical: 0 = exact f32, the default and the parity reference; 1 = opt-in split precision -- activations and weights as f16 hi/lo pairs, three v_mfma_f32_32x32x16_f16 per f32 product, f32 accumulation; passes the reference fixtures at the f32 tolerance, 2.5x faster; an activation beyond the f16 range makes the call fail with OG_ERANGE), "h_square" 0|1 (its wave tiling), "stream" 0|1 (og_unet_segment_u8 through the streaming engine, default 1; 0 = whole batch staged at once), "dual" 0|1 (micro-batches of one call alternate over extra lanes = streams/arenas, so that launch tails overlap) with "lanes" 0..3 (0 = 3 lanes up to 16 frames per launch, else 2), and
  * "splitk" 0|1 (1 = launches that would fill < 1/4 of the chip split K across workgroups; sums
  * are taken in a fixed order, so results are deterministic but differ in the last bits from the
- * unsplit order). */
+ * unsplit order), "splitk_nt1" 0|1 (split launches of 64-column layers on 32-column tiles), "splitk_min_steps" 1..9.
+ * "wino" 0|1 [1] (NOT bit-identical: 1 = the 3x3 convs of every kernel chain whose micro-batch fills the chip -- 32 frames at
+ * 256x256 -- run in Winograd F(2x2,3x3) form, all f32: 16 MFMA multiplies per 2x2 output window and channel pair instead of 36,
+ * transforms in f32 adds; same reference fixtures, same 5e-5 tolerance, measured closer to the reference than the direct form;
+ * 0 = the direct kernels everywhere; smaller micro-batches always take the direct kernels), "wino_first" 0|1 (on such chains
+ * the first layer runs unfused so that the second conv takes the Winograd kernel). */
 int og_unet_set_option(og_unet* h, const char* name, int value);
 
 /* HIP-event timing on the handle's stream (bench.py's roofline leg). */
