@@ -497,3 +497,43 @@ def test_occupancy_kernels_on_partial_tiles_large_batch():
     m2.set_option("splitk", 0)
     _, areas2b, logits2b = m2.segment(fr2[:6], want_logits=True)
     assert np.array_equal(logits2[:6], logits2b) and np.array_equal(areas2[:6], areas2b)
+
+
+@pytest.mark.parametrize("feats,shape,B", [((32, 64), (128, 256), 16),       # every layer tiles: wino<1> x 3, wino<2> x 5
+                                           ((32, 64), (96, 160), 24),        # bottleneck 24x40 does not tile by 16 -> direct
+                                           ((64, 128), (48, 64), 64),        # 64-wide first level on 48 rows: wino<2> from layer 2 on
+                                           ((40, 80), (64, 64), 128),        # padded channel slots (40 -> 64 columns; 80 -> 96 and 160: 32-column tiles)
+                                           ((32, 64), (512, 512), 4)])      # large frames: a micro-batch of 4 fills the chip
+def test_winograd_form_against_oracle_and_direct_form(feats, shape, B):
+    """Every micro-batch that fills the chip runs its 3x3 convs in Winograd F(2x2,3x3) form (k_conv_wino<2> on 16x16-pixel
+    tiles, k_conv_wino<1> on 32x16 ones), layer by layer where the map tiles, the direct kernels elsewhere -- against the
+    oracle at the usual tolerance, against the direct form of the same chain, deterministic, and with the kernels asserted."""
+    import torch
+    from oracle import unet_oracle as O
+    H, W = shape
+    sd = synth.make_unet_state_dict(feats, seed=H + W + len(feats), head_scale=2.0, head_bias=-0.4)
+    m = make_model(sd, feats)
+    fr = synth.random_gray_frames(B, H, W, seed=B + H)
+    m.set_chunk(B)
+    masks, areas, logits = m.segment(fr, want_logits=True)
+    masks_b, areas_b, logits_b = m.segment(fr, want_logits=True)
+    assert np.array_equal(logits, logits_b) and np.array_equal(areas, areas_b)
+    kernels = [p["kernel"] for p in m.profile(torch.from_numpy(fr).to("cuda:0"), B, H, W, reps=1)]
+    assert any(k.startswith("k_conv_wino") for k in kernels), kernels
+    m.set_option("wino", 0)
+    masks_d, areas_d, logits_d = m.segment(fr, want_logits=True)
+    assert not any(k.startswith("k_conv_wino") for k in (p["kernel"] for p in m.profile(torch.from_numpy(fr).to("cuda:0"), B, H, W, reps=1)))
+    n_ref = min(B, 3)
+    ref_mask, ref_logits = O.segment_frames(sd, fr[:n_ref], backend="torch")
+    scale = max(1.0, np.abs(ref_logits).max())
+    assert np.abs(logits[:n_ref] - ref_logits).max() <= TOL * scale
+    assert np.abs(logits_d[:n_ref] - ref_logits).max() <= TOL * scale
+    assert np.abs(logits - logits_d).max() <= TOL * scale
+    diff = (masks[:n_ref] > 0) != (ref_mask > 0)
+    assert np.all(np.abs(ref_logits[diff]) <= TOL * scale)
+    assert np.array_equal(areas, (masks > 0).reshape(B, -1).sum(1))
+    # half the micro-batch (below the threshold for most of these shapes: direct kernels whatever the option says)
+    m.set_option("wino", 1)
+    m.set_chunk(max(1, B // 2))
+    _, _, logits_h = m.segment(fr[: max(1, B // 2)], want_logits=True)
+    assert np.abs(logits_h - logits_d[: max(1, B // 2)]).max() <= TOL * scale
