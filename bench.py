@@ -256,6 +256,9 @@ def main() -> None:
                                    "gray frames resident in HBM, int32 areas left on the device",
                        "frames_per_step_all_gpus": n_total, "frames_this_rank": F, "frames_per_launch": args.chunk,
                        "hip_graphs": not args.no_graphs, "lanes": args.lanes,
+                       "conv_form": ("direct 3x3 convs (--option wino=0)" if any(o == "wino=0" for o in args.option) else
+                                     "3x3 convs in Winograd F(2x2,3x3) form: f32 transforms, f32 MFMA, 16/36 of the direct form's multiplies; "
+                                     "same reference fixtures and tolerance as the direct kernels (--option wino=0)"),
                        "sharding": (f"{'one video' if strong else 'frames'} x{world} (shard_range), all_gather(int32 area) per step over {backend}" if world > 1 else "none"),
                        "flop_per_frame": model.flops_per_frame(256, 256)},
             "tflops": round(fps * model.flops_per_frame(256, 256) / 1e12, 2),
