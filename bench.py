@@ -14,6 +14,7 @@ the area-waveform all-gather (RCCL) when N > 1.  ONE JSON line:
   roofline        dominant kernel against the f32 MFMA peak, HIP events around every launch, live in this run.  The 64-column
                   3x3 layers run in Winograd F(2x2,3x3) form (all f32): `achieved` counts the direct form's FLOPs,
                   `mfma_executed` the 16/36 of them the matrix pipe issues.
+  direct_form     the same chain on the direct 3x3 kernels (option wino=0): frames/s, chain fraction and dominant-kernel roofline.
   cpu_baseline    the oracle's torch-CPU restatement of the same loop body on the host cores, 1 thread and all cores.
 
   python bench.py                                   # 1 GPU, 512 frames per step
@@ -142,6 +143,7 @@ def main() -> None:
                     help="2 = odd micro-batches on the twin handle's stream (default); 1 = single stream "
                          "(per-kernel durations under rocprofv3 are then not inflated by the other lane)")
     ap.add_argument("--no-latency-mode", action="store_true", help="skip the 1-frame-per-launch leg")
+    ap.add_argument("--no-direct-form", action="store_true", help="skip the leg that times the same chain on the direct 3x3 kernels (wino=0)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="og_unet_set_option knob for A/B measurements (results are bit-identical across them), repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -344,6 +346,26 @@ def main() -> None:
 
     if world == 1 and F and not args.no_roofline:
         out["roofline"], out["per_kernel_ms"] = roofline("k_conv_", PEAK_F32_MFMA_TFLOPS if not any(o.startswith("precision=1") for o in args.option) else round(PEAK_F16_MFMA_TFLOPS / 3, 1))
+    if world == 1 and F and not args.no_direct_form and not any(o.startswith(("wino=", "precision=")) for o in args.option):
+        # The same chain with the DIRECT 3x3 kernels (round 1's arithmetic, 36 multiplies per output window instead of 16): what
+        # every launch that does not fill the chip takes, and the continuity figure against the f32 MFMA peak
+        model.set_option("wino", 0)
+        for _ in range(args.warmup):
+            step()
+        fence(); t1 = time.perf_counter()
+        for _ in range(args.steps):
+            wd = step()
+        fence(); ed = time.perf_counter() - t1
+        fpsd = args.steps * n_total / ed
+        wd = wd.clone()
+        rld, perd = roofline("k_conv_mfma_o", PEAK_F32_MFMA_TFLOPS)
+        out["direct_form"] = {"value": round(fpsd, 1), "unit": "frames/s", "ms_per_step": round(1e3 * ed / args.steps, 3),
+                              "tflops": round(fpsd * model.flops_per_frame(256, 256) / 1e12, 2),
+                              "chain_frac_mfma": round(fpsd * model.flops_per_frame(256, 256) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                              "frames_whose_area_differs_from_headline": int((wd != wave).sum()),
+                              "max_area_difference_px": int((wd.to(torch.int64) - wave.to(torch.int64)).abs().max()),
+                              "roofline": rld, "per_kernel_ms": perd}
+        model.set_option("wino", 1)
     if world == 1 and F and not args.no_split_precision and not any(o.startswith("precision=") for o in args.option):
         # Exploratory secondary mode, NEVER the headline: f16 hi/lo operand pairs, 3 x v_mfma_f32_32x32x16_f16 per f32 product,
         # f32 accumulation; passes the same reference fixtures at the same tolerance (tests/test_gpu_split_precision.py)
