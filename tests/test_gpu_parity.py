@@ -214,9 +214,9 @@ def test_split_k_latency_mode(trained, full):
         _, a_fu, l_fu = mf.segment(framesf, want_mask=False, want_logits=True)
         assert np.array_equal(l_fu, l_sep) and np.array_equal(a_fu, a_sep)
     assert np.array_equal(l_sep, l1)
-    # 32-column tiles on split launches (default) / the layer's own 64-column tiles, K parts of 9 or 3 (chunk, tap) steps:
+    # 32-column tiles on split launches (default) / the layer's own 64-column tiles, K parts of 3 (default) or 9 (chunk, tap) steps:
     # other part boundaries, so other roundings -- all inside the tolerance, each deterministic
-    for nt1, steps in ((0, 9), (1, 3), (0, 3)):
+    for nt1, steps in ((0, 9), (1, 9), (0, 3)):
         mf.set_option("splitk_nt1", nt1)
         mf.set_option("splitk_min_steps", steps)
         _, a_v, l_v = mf.segment(framesf, want_mask=False, want_logits=True)
@@ -224,7 +224,7 @@ def test_split_k_latency_mode(trained, full):
         assert np.array_equal(l_v, l_v2) and np.array_equal(a_v, a_v2)
         assert np.abs(l_v - l0).max() <= TOL, (nt1, steps)
     mf.set_option("splitk_nt1", 1)
-    mf.set_option("splitk_min_steps", 9)
+    mf.set_option("splitk_min_steps", 3)
     mf.set_chunk(32)
     assert np.abs(l1.reshape(8, -1)[:, gf["sample_idx"]] - gf["logits_samples"]).max() <= TOL
     assert np.all(np.abs(a0.astype(int) - a1.astype(int)) <= ((l0 > 0) != (l1 > 0)).reshape(8, -1).sum(1))
