@@ -248,3 +248,75 @@ def test_activation_beyond_the_f16_range_fails_loudly_in_split_precision():
     m.sync()                                                          # the flag is cleared by the report
     ok = make_model(sd, feats, precision=1)                           # ordinary weights: no error
     ok.segment(fr)
+
+
+def test_randomised_entry_point_matrix_on_chip_filling_batches():
+    """The same sweep where the micro-batch fills the chip, so that the chain takes the Winograd form (k_conv_wino<1> / <2>,
+    layer by layer where the map tiles by 32x16 / 16x16): frame size, batch, micro-batch, lanes, graphs, boxes, host /
+    streamed / device entry points -- each configuration against the CPU oracle, and at least one of them must really have
+    run the Winograd kernels (its logits differ from the direct form's in the last bits)."""
+    import torch
+
+    from oracle import unet_oracle as O
+    from openglottal_amd.utils import normalize_box
+
+    rs = np.random.RandomState(4242)
+    feats = (32, 64)
+    sd = synth.make_unet_state_dict(feats, seed=78, head_scale=2.5, head_bias=-0.2)
+    m = make_model(sd, feats, precision=0)
+    dev = torch.device("cuda", 0)
+    cache = {}
+    saw_winograd = 0
+    for it in range(24):
+        H, W = [(32, 64), (64, 64), (64, 32), (96, 64), (32, 160), (40, 48)][rs.randint(6)]
+        B = int(rs.choice([130, 160, 256, 300]))
+        key = (H, W, B)
+        if key not in cache:
+            fr = rs.randint(0, 256, (B, H, W), dtype=np.uint8)
+            cache[key] = (fr,) + O.segment_frames(sd, fr, backend="torch")
+        fr, ref_mask, ref_logits = cache[key]
+        m.set_chunk(int(rs.choice([128, 256, 512])))
+        m.set_option("lanes", int(rs.randint(4)))
+        m.set_graphs(bool(rs.randint(2)))
+        m.set_option("stream", int(rs.randint(2)))
+        boxes = None
+        if rs.randint(2):
+            boxes = np.array([normalize_box((int(rs.randint(-5, W)), int(rs.randint(-5, H)), int(rs.randint(0, W + 9)), int(rs.randint(0, H + 9))), W, H)
+                              for _ in range(B)], np.int32)
+            boxes[rs.randint(B)] = -1
+        how = int(rs.randint(3))
+        if how == 0:
+            masks, areas, logits = m.segment(fr, boxes=boxes, want_logits=True)
+        elif how == 1:
+            masks, areas = m.segment_stream(fr, boxes=boxes, want_mask=True)
+            logits = None
+        else:
+            d_f = torch.from_numpy(fr).to(dev)
+            d_a = torch.zeros(B, dtype=torch.int32, device=dev)
+            d_m = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
+            d_l = torch.zeros((B, H, W), dtype=torch.float32, device=dev)
+            m.segment_dev(d_f, B, H, W, d_a, boxes_dev=None if boxes is None else torch.from_numpy(boxes).to(dev), mask_dev=d_m, logits_dev=d_l)
+            m.sync()
+            masks, areas, logits = d_m.cpu().numpy(), d_a.cpu().numpy(), d_l.cpu().numpy()
+        cfg = (it, H, W, B, how)
+        scale = max(1.0, np.abs(ref_logits).max())
+        if logits is not None:
+            assert np.abs(logits - ref_logits).max() <= TOL * scale, cfg
+            if it % 4 == 0:
+                m.set_option("wino", 0)
+                _, _, logits_d = m.segment(fr, want_logits=True)
+                m.set_option("wino", 1)
+                assert np.abs(logits_d - ref_logits).max() <= TOL * scale, cfg
+                saw_winograd += int(not np.array_equal(logits_d, logits))
+        diff = (masks > 0) != (ref_mask > 0)
+        assert np.all(np.abs(ref_logits[diff]) <= TOL * scale), cfg
+        for i in range(B):
+            if boxes is None:
+                want = int((masks[i] > 0).sum())
+            elif boxes[i][0] < 0:
+                want = 0
+            else:
+                x1, y1, x2, y2 = boxes[i]
+                want = int((masks[i][y1:y2, x1:x2] > 0).sum())
+            assert int(areas[i]) == want, cfg + (i,)
+    assert saw_winograd >= 1
