@@ -18,8 +18,10 @@ the area-waveform all-gather (RCCL) when N > 1.  ONE JSON line:
   cpu_baseline    the oracle's torch-CPU restatement of the same loop body on the host cores, 1 thread and all cores.
 
   python bench.py                                   # 1 GPU, 512 frames per step
-  python bench.py --total-frames 10000              # C4's workload on however many ranks the launcher started (strong scaling)
+  python bench.py --gpus 8                          # starts its own 8 ranks (one process per GPU, RCCL), relays rank 0's line
+  python bench.py --gpus 8 --total-frames 10000     # config C4: ONE 10 000-frame video sharded over the ranks (strong scaling)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+                                                    # the same ranks started by an outer launcher (RANK / WORLD_SIZE set): used as they are
 """
 import argparse
 import hashlib
@@ -128,6 +130,79 @@ def cpu_baseline(sd, budget_s: float = 10.0, max_frames: int = 256):
                       "one frame per call (BGR->gray, /255, oracle.forward_torch fp32, sigmoid, >0.5, sum), as features.py:234-238"}
 
 
+def launch_command(argv: list[str], n: int, port: int) -> list[str]:
+    """The command `--gpus N` expands to when no launcher has set RANK / WORLD_SIZE: one process per GPU under
+    torch.distributed.run on this node, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def pick_json_line(text: str) -> str | None:
+    """Rank 0's result line among whatever else the children wrote to stdout."""
+    for line in reversed(text.splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}") and '"metric"' in line:
+            return line
+    return None
+
+
+def self_launch(argv: list[str], n: int) -> int:
+    """Parent of `python bench.py --gpus N` (N > 1, no RANK in the environment).  It never touches the GPU (no torch import, no
+    HIP call): it starts N fresh ranks as CHILD processes, lets their stderr through, relays rank 0's JSON line and returns the
+    launcher's exit code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    p = subprocess.run(launch_command(argv, n, port), stdout=subprocess.PIPE, env=env, text=True)
+    line = pick_json_line(p.stdout or "")
+    if line is not None:
+        print(line, flush=True)
+    elif p.stdout:
+        sys.stderr.write(p.stdout)
+    if p.returncode != 0:
+        sys.stderr.write(f"bench.py: a rank failed (launcher exit code {p.returncode})\n")
+        return p.returncode
+    if line is None:
+        sys.stderr.write("bench.py: the ranks printed no result line\n")
+        return 1
+    return 0
+
+
+def plumbing_selftest(args) -> int:
+    """What a rank does around the device work, without the device work (tests/test_bench_launcher.py)."""
+    import torch
+    import torch.distributed as dist
+
+    from openglottal_amd.dist import all_gather_areas, env_rank_world, shard_range
+
+    rank, _, world = env_rank_world()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        dist.init_process_group("gloo")
+    if rank == args.plumbing_fail_rank:
+        return 3
+    n_total = args.total_frames if args.total_frames > 0 else args.frames * world
+    lo, hi = shard_range(n_total, rank, world) if args.total_frames > 0 else (rank * args.frames, (rank + 1) * args.frames)
+    local = torch.arange(lo, hi, dtype=torch.int32) % 1000
+    wave = all_gather_areas(local, n_total) if world > 1 else local
+    ok = bool(torch.equal(wave.to(torch.int32), torch.arange(n_total, dtype=torch.int32) % 1000))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing selftest (no device work; not a measurement)", "world": world, "n_gpus": world,
+                          "frames_per_step_all_gpus": n_total, "waveform_ok": ok, "scaling": "strong" if args.total_frames > 0 else "weak"}), flush=True)
+    return 0 if ok else 4
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,7 +226,17 @@ def main() -> None:
     ap.add_argument("--no-host-inclusive", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the Dice-delta leg on the reference fixture")
     ap.add_argument("--no-split-precision", action="store_true", help="skip the exploratory split-precision leg")
+    ap.add_argument("--plumbing-selftest", action="store_true",
+                    help="CPU-only check of the N > 1 plumbing (self-launch, rendezvous, shard_range, ragged all-gather over gloo, "
+                         "JSON relay, exit codes) with NO device work: the line it prints says so and is not a measurement")
+    ap.add_argument("--plumbing-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))   # one process per GPU; this parent has not touched the GPU
+
+    if args.plumbing_selftest:
+        raise SystemExit(plumbing_selftest(args))
 
     # stdout carries ONE JSON line: libraries that chat on file descriptor 1 (RCCL prints a version banner at communicator
     # creation, gloo its connection report) are sent to stderr until the line is printed
@@ -167,10 +252,8 @@ def main() -> None:
     from openglottal_amd.dist import all_gather_areas, env_rank_world, shard_range
 
     rank, local_rank, world = env_rank_world()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
     # OG_BENCH_BACKEND=gloo: rehearsal of the N > 1 logic (sharding, ragged last rank, gather, max-over-ranks timing) with several
     # ranks SHARING one GPU (RCCL refuses two ranks on one device): ranks map onto the visible devices round-robin and the tiny
     # collectives go through host memory.  The product path and the driver's runs use nccl (= RCCL over xGMI).
@@ -220,10 +303,14 @@ def main() -> None:
     del bgr_dev
     area = torch.zeros(max(F, 1), dtype=torch.int32, device=dev)
 
+    busy = [0.0]   # this rank's own time in the frame loop (launch -> its last area counted), without the waits for other ranks
+
     def step():
+        t_in = time.perf_counter()
         if F:
             model.segment_dev(frames, F, 256, 256, area)
         model.sync()  # kernels run on the handle's stream; the collective on torch's
+        busy[0] += time.perf_counter() - t_in
         return all_gather_areas(area[:F].to(coll_dev), n_total, force=force_dist) if (world > 1 or force_dist) else area[:F]
 
     def fence():
@@ -234,15 +321,21 @@ def main() -> None:
     for _ in range(args.warmup):
         wave = step()
     fence()
+    busy[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wave = step()
     fence()
     el = time.perf_counter() - t0
+    per_rank = [[F, busy[0]]]
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+        mine = torch.tensor([float(F), busy[0]], dtype=torch.float64, device=coll_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[int(v[0].item()), float(v[1].item())] for v in allr]
     assert wave.numel() == n_total and int(wave.min()) >= 0
     wave = wave.clone()   # `area` is reused by the legs below
 
@@ -264,9 +357,17 @@ def main() -> None:
                        "sharding": (f"{'one video' if strong else 'frames'} x{world} (shard_range), all_gather(int32 area) per step over {backend}" if world > 1 else "none"),
                        "flop_per_frame": model.flops_per_frame(256, 256)},
             "tflops": round(fps * model.flops_per_frame(256, 256) / 1e12, 2),
+            # what the collective layer itself reports, and every rank's own rate (frames of its shard / its own time in the
+            # frame loop, waits for the other ranks excluded): the scaling curve's raw material
+            "world": world,
+            "collective": ({"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None}
+                           if (world > 1 or force_dist) else None),
+            "per_rank_fps": [round(args.steps * f / b, 1) if b > 0 else 0.0 for f, b in per_rank],
+            "per_rank_frames": [int(f) for f, _ in per_rank],
         }
         # whole-chain fractions (wall clock): binding roof = f32 MFMA; HBM with SURVEY 8(d)'s layer-boundary model
-        out["chain_frac_mfma"] = round(out["tflops"] / PEAK_F32_MFMA_TFLOPS / world, 4)   # algorithmic FLOPs: the Winograd layers issue 16/36 of theirs
+        out["chain_algorithmic_over_mfma_peak"] = round(out["tflops"] / PEAK_F32_MFMA_TFLOPS / world, 4)   # algorithmic FLOPs (the Winograd layers issue 16/36 of theirs): not a roofline fraction
         out["chain_frac_hbm_layer_boundary_model"] = round(fps * LAYER_BOUNDARY_BYTES_PER_FRAME / PEAK_HBM_BYTES / world, 4)
     if world == 1 and not args.no_parity:
         # BASELINE metric, second half ("Dice delta vs CPU ref"): the 128-frame full-width fixture that the reference's own
@@ -288,58 +389,87 @@ def main() -> None:
                              "dice_delta_vs_cpu_ref_max": round(dd, 8), "flipped_mask_pixels": flips, "of_pixels": 128 * 65536,
                              "frames_with_area_difference": int((ar.astype(np.int64) != g["areas"]).sum()),
                              "note": "every flipped pixel sits where the reference's own logit is within 5e-5 of zero (tests/test_gpu_bench_config.py)"}
-    if world == 1 and F and not args.no_host_inclusive:
-        # SURVEY 8(d) / benchmark_video_speed.py:83-109: first H2D enqueue -> last area on the host, BGR->gray inside
+    if not args.no_host_inclusive:
+        # SURVEY 8(d) / benchmark_video_speed.py:83-109: first H2D enqueue -> last area on the host, BGR->gray inside; at N > 1
+        # every rank streams ITS shard from its own pinned host memory and the areas are all-gathered inside the region
         hf = bgr_host[:F]
-        model.segment_stream(hf[:min(F, 2 * args.chunk)])   # warm-up: ring allocation, graphs
+        if F:
+            model.segment_stream(hf[:min(F, 2 * args.chunk)])   # warm-up: ring allocation, graphs
         reps = max(1, min(args.steps, 5))
         fence(); t1 = time.perf_counter()
         for _ in range(reps):
-            _, a_host = model.segment_stream(hf)
+            a_host = model.segment_stream(hf)[1] if F else np.zeros(0, np.int32)
+            if world > 1 or force_dist:
+                w_host = all_gather_areas(torch.from_numpy(a_host).to(coll_dev), n_total, force=force_dist)
+        fence()
         eh = time.perf_counter() - t1
-        assert np.array_equal(a_host, wave.cpu().numpy())       # same integers as the resident leg
-        out["host_inclusive"] = {"value": round(reps * F / eh, 1), "unit": "frames/s", "frames": F, "passes": reps,
-                                 "region": "pinned host BGR u8 [F,256,256,3] -> H2D -> BGR->gray (device) -> U-Net -> int32 areas on the host "
-                                           "(og_unet_stream_u8: ring of pinned micro-batches, copies under the kernel chains)",
-                                 "pcie_bytes_per_frame": 256 * 256 * 3 + 4}
-    if world == 1 and F and not args.no_latency_mode:
-        # BASELINE configs[1] wording "batch=1": one frame per kernel chain, frames still resident in HBM
+        if world > 1:
+            t = torch.tensor([eh], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            eh = float(t.item())
+            assert torch.equal(w_host.cpu().to(torch.int32), wave.cpu().to(torch.int32))
+        else:
+            assert np.array_equal(a_host, wave.cpu().numpy())       # same integers as the resident leg
+        if rank == 0:
+            out["host_inclusive"] = {"value": round(reps * n_total / eh, 1), "unit": "frames/s", "frames": n_total, "passes": reps,
+                                     "region": "pinned host BGR u8 [F,256,256,3] -> H2D -> BGR->gray (device) -> U-Net -> int32 areas on the host "
+                                               "(og_unet_stream_u8: ring of pinned micro-batches, copies under the kernel chains)"
+                                               + (", + all_gather of the areas; max over ranks" if world > 1 else ""),
+                                     "pcie_bytes_per_frame": 256 * 256 * 3 + 4}
+
+    def one_frame_per_chain():
         n1 = min(F, 256)
         model.set_chunk(1)
         model.segment_dev(frames, n1, 256, 256, area); model.sync()
         fence(); t1 = time.perf_counter()
         model.segment_dev(frames, n1, 256, 256, area); model.sync()
         fence(); e1 = time.perf_counter() - t1
-        out["latency_mode"] = {"frames_per_launch": 1, "value": round(n1 / e1, 1), "unit": "frames/s", "frames": n1}
         model.set_chunk(args.chunk)
+        return {"frames_per_launch": 1, "value": round(n1 / e1, 1), "unit": "frames/s", "frames": n1}, area[:n1].clone()
+
+    if world == 1 and F and not args.no_latency_mode:
+        # BASELINE configs[1] wording "batch=1": one frame per kernel chain, frames still resident in HBM.  Same (canonical)
+        # arithmetic as the headline, so the same integers
+        out["latency_mode"], a1 = one_frame_per_chain()
+        assert torch.equal(a1, wave[:a1.numel()].to(a1.device))
+        out["latency_mode"]["note"] = "canonical form (identical areas to the headline leg, asserted)"
+        if not any(o.startswith(("wino=", "splitk=", "precision=")) for o in args.option):
+            # opt-in, non-canonical: direct kernels with K split over workgroups (round 2's latency path); a frame's logits
+            # then depend on the size of its launch, which is why it is not the default
+            model.set_option("wino", 0); model.set_option("splitk", 1)
+            out["latency_mode_optin_splitk"], a1s = one_frame_per_chain()
+            out["latency_mode_optin_splitk"]["frames_whose_area_differs_from_canonical"] = int((a1s != a1).sum())
+            model.set_option("wino", 1); model.set_option("splitk", 0)
     def roofline(kernel_prefix, peak_equiv, note=None):
         """Dominant kernel (largest share of chain time among kernels starting with `kernel_prefix`) from HIP events around
-        every launch of one eager chain; `achieved` = algorithmic (f32-equivalent) FLOPs of its launches / their time."""
+        every launch of one eager chain.  `achieved` / `frac` = MFMA FLOPs the kernel EXECUTES / its time, against the dense peak
+        of the instruction it issues: a fraction of a roof, <= 1 by construction.  A Winograd launch executes 16/36 of the
+        direct form's (= SURVEY 8(d)'s algorithmic) multiplies: `algorithmic_tflops` / `algorithmic_over_peak` carry that count."""
         B = min(args.chunk, F)
         prof = model.profile(frames, B, 256, 256, reps=max(3, min(20, args.steps)))
+        ex = lambda p: p["flops"] / (2.25 if p["kernel"].startswith("k_conv_wino") else 1.0)
         per = {}
         for p in prof:
             per[p["kernel"]] = per.get(p["kernel"], 0.0) + p["ms"]
         name = max((k for k in per if k.startswith(kernel_prefix)), key=lambda k: per[k])
         dom = [p for p in prof if p["kernel"] == name]
-        fl, ms = sum(p["flops"] for p in dom), sum(p["ms"] for p in dom)
-        tot_ms = sum(p["ms"] for p in prof)
-        ach = fl / (ms * 1e-3) / 1e12
+        fl, fx, ms = sum(p["flops"] for p in dom), sum(ex(p) for p in dom), sum(p["ms"] for p in dom)
+        tot_ms, tot_fl, tot_fx = sum(p["ms"] for p in prof), sum(p["flops"] for p in prof), sum(ex(p) for p in prof)
+        ach, alg = fx / (ms * 1e-3) / 1e12, fl / (ms * 1e-3) / 1e12
         tr = pmc_traffic(name, B)   # HBM bytes per launch from the committed rocprofv3 PMC passes (or None)
         r = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak_equiv,
              "unit": "TFLOP/s", "frac": round(ach / peak_equiv, 4),
+             "algorithmic_tflops": round(alg, 2), "algorithmic_over_peak": round(alg / peak_equiv, 4),
              "traffic": (tr or {}).get("hbm_bytes_per_launch") if (tr or {}).get("same_kernels") else None,
              "traffic_detail": tr, "launches_per_chain": len(dom), "avg_launch_ms": round(ms / len(dom), 4),
              "share_of_chain_time": round(ms / tot_ms, 3), "frames_per_launch": B, "chain_ms": round(tot_ms, 3),
+             "chain": {"executed_tflops": round(tot_fx / (tot_ms * 1e-3) / 1e12, 2), "frac": round(tot_fx / (tot_ms * 1e-3) / 1e12 / peak_equiv, 4),
+                       "algorithmic_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                       "note": "all launches of one chain on one lane, HIP events per launch"},
              "kernel_source_sha": kernel_source_sha()}
         if name.startswith("k_conv_wino"):
-            # Winograd F(2x2,3x3): 16 multiplies per 2x2 output window and channel pair instead of the direct form's 36.
-            # `achieved` counts the ALGORITHMIC (direct-form) FLOPs, as SURVEY 8(d) defines them, so `frac` above 1 is the
-            # algorithmic saving; the matrix pipe itself executes achieved / 2.25
-            r["mfma_executed"] = {"achieved": round(ach / 2.25, 2), "frac": round(ach / 2.25 / peak_equiv, 4), "unit": "TFLOP/s",
-                                  "note": "MFMA FLOPs actually issued (16/36 of the direct form's) against the same dense f32 MFMA peak"}
-            note = (note + "; " if note else "") + ("Winograd F(2x2,3x3) in f32: achieved = direct-form (algorithmic) FLOP/s, so frac > 1 "
-                                                    "is possible; mfma_executed is the matrix pipe's own utilisation")
+            note = (note + "; " if note else "") + ("Winograd F(2x2,3x3) in f32: achieved / frac count the MFMA FLOPs issued (16/36 of the direct form's); "
+                                                    "algorithmic_* count SURVEY 8(d)'s direct-form FLOPs")
         if note:
             r["note"] = note
         return r, {k: round(v, 4) for k, v in per.items()}
@@ -361,9 +491,10 @@ def main() -> None:
         rld, perd = roofline("k_conv_mfma_o", PEAK_F32_MFMA_TFLOPS)
         out["direct_form"] = {"value": round(fpsd, 1), "unit": "frames/s", "ms_per_step": round(1e3 * ed / args.steps, 3),
                               "tflops": round(fpsd * model.flops_per_frame(256, 256) / 1e12, 2),
-                              "chain_frac_mfma": round(fpsd * model.flops_per_frame(256, 256) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                              "frames_whose_area_differs_from_headline": int((wd != wave).sum()),
+                              "chain_frac_mfma": round(fpsd * model.flops_per_frame(256, 256) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),   # direct form: executed = algorithmic
+                              "frames_whose_area_differs_from_canonical_form": int((wd != wave).sum()),
                               "max_area_difference_px": int((wd.to(torch.int64) - wave.to(torch.int64)).abs().max()),
+                              "note": "another arithmetic form (option wino=0), compared ACROSS forms: both inside the reference's own noise band",
                               "roofline": rld, "per_kernel_ms": perd}
         model.set_option("wino", 1)
     if world == 1 and F and not args.no_split_precision and not any(o.startswith("precision=") for o in args.option):

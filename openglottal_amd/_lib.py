@@ -108,6 +108,11 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)  # AttributeError if a symbol is missing: also loud
             fn.restype = res
             fn.argtypes = args
+        ver = (l.og_version() or b"").decode()
+        if "store_nop=1" not in ver and os.environ.get("OPENGLOTTAL_HIP_ALLOW_AUDIT_BUILD") != "1":
+            # an audit build (-DOG_STORE_NOP=0, tools/epilogue_fence_audit.sh) reproduces a hardware store hazard and computes
+            # wrong lanes: never let OPENGLOTTAL_HIP_LIB point the product at one
+            raise OpenGlottalHipError(f"{LIB_PATH} reports {ver!r}: not a production build (store_nop=1 missing); refusing to load it")
         _lib = l
     return _lib
 

@@ -111,9 +111,12 @@ struct og_unet {
     int xcd_group = 1;   // see LaunchCtx::xcd_group
     int splitk_occ = 1;  // split-K parts on the occupancy kernel (0: persistent kernel)
     int splitk_min_steps = 3;  // smallest K part of a split 3x3 conv, in (chunk, tap) steps (9 = one channel chunk; 3 measured +1.4 % at one frame per chain)
-    int wino = 1;        // 64-column 3x3 layers in Winograd F(2x2,3x3) form (k_conv_wino, all f32) -- decided once per kernel chain
+    int wino = 1;        // 3x3 layers in Winograd F(2x2,3x3) form (k_conv_wino, all f32): the CANONICAL arithmetic of this library.
+                         // Which layers take it is a function of the handle's options and of (H, W) alone -- never of the micro-batch
+                         // size, the lane, the shard or the entry point -- so a frame's mask is a function of the frame only
+                         // (features.py:234-238 has no cross-frame state either).  0: the direct kernels for every layer.
     int wino_first = 1;  // Winograd chains: first layer unfused so that the second conv takes k_conv_wino<1>
-    bool wino_chain = false;   // (run_chunk): when the chain's deepest such layer fills the chip with one 16x16 tile per CU
+    bool wino_chain = false;   // (pick_chain_form) wino && precision == 0 && conv_impl == 2
     int splitk_nt1 = 1;  // split 3x3 launches on 32-column tiles (twice the workgroups, half the MFMAs per K part)
     int splitk_slots = 1, splitk_div = 2;  // occupancy split-K: target workgroups per CU; split when the launch fills < 1/div of them
                                            // (round-2 sweep, one to three lanes, both precisions: 1 / 2 beats round 1's 2 / 4 at 1-4 frames per launch)
@@ -142,7 +145,8 @@ struct og_unet {
     } fuse;
     int convt_occ = 1;   // with conv_impl >= 2: run the transposed convs on the occupancy variant too
     int tile_h = 0;      // 0 auto (16x16 tiles for 64-channel-tile layers at <= 64x64 pixels, else 8x16) | 8 | 16
-    int splitk = 1;      // allow split-K on launches that would fill < 1/4 of the chip (latency mode)
+    int splitk = 0;      // OPT-IN (non-canonical): split K over workgroups on launches that would fill < 1/div of the chip.  It changes the
+                         // summation order, so a frame's logits then depend on how many frames share its launch; off by default
     float* d_partial = nullptr;
     int* d_tile_counter = nullptr;   // split-K arrival counters (fused reduce), zero between launches
     int splitk_fused = 1;            // last-arriving K part reduces + runs the epilogue (0: separate k_splitk_epilogue launch)
@@ -773,7 +777,10 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     }
     int impl = h->conv_impl;
     int NTu = L.NT;   // column sub-tiles per workgroup of THIS launch (32-column tiles on split 3x3 launches, see splitk_nt1)
-    if (impl == 1 || impl == 2) {
+    // Winograd form of this layer?  Decided from the handle's options and the layer's shape only (B plays no part).
+    const bool use_wino = L.mode == 0 && h->wino_chain && L.d_ww != nullptr && full16 && (L.NT == 2 || in.H % 32 == 0) &&
+                          (a.head_w == nullptr || L.NT == 1);
+    if (!use_wino && (impl == 1 || impl == 2)) {
         const bool sk_occ = (impl == 2 && h->splitk_occ);
         const int nt = (L.mode == 0) ? L.Cout_p / (32 * L.NT) : 4 * L.Cout_p / 64;
         const int tiles8 = B * a.tiles_x * ((in.H + 7) / 8);
@@ -818,7 +825,7 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         const int n_ntiles = L.Cout_p / (32 * L.NT);
         if (out.H != in.H || out.W != in.W) return fail(OG_EINVAL, "conv shape mismatch");
         const double fl = 2.0 * px * 9.0 * L.Cin * L.Cout;
-        if (h->wino_chain && L.d_ww != nullptr && full16 && (L.NT == 2 || in.H % 32 == 0) && (a.head_w == nullptr || L.NT == 1) && a.ksplit == 1) {
+        if (use_wino) {
             a.tiles_y = in.H / (32 / L.NT);
             a.n_spatial = B * a.tiles_x * a.tiles_y;
             a.wpk = L.d_ww;
@@ -1067,12 +1074,11 @@ int enqueue_head(og_unet* h, int B, int H, int W, float thr, const int32_t* boxe
 
 // One chunk of B (<= capB) frames.  Body eager, or replayed from a cached hipGraph
 // (launch-bound at small B otherwise: 5*L+2 launches, MI355X_MICROARCH.md "graph-replay-floor").
-// Winograd form for the whole chain or for none of it: the deepest map decides (it has the fewest tiles), so that results do
-// not change from layer to layer with the micro-batch size -- every micro-batch that fills the chip takes it.
-void pick_chain_form(og_unet* h, int B, int H, int W) {
-    const int Hd = H >> h->L, Wd = W >> h->L;
-    const long long deep_tiles = (long long)B * ((Hd + 15) / 16) * ((Wd + 15) / 16) * (cp32(2 * h->features[h->L - 1]) / 64);
-    h->wino_chain = h->wino && h->precision == 0 && h->conv_impl == 2 && deep_tiles >= h->n_cu;
+// The arithmetic form of the chain is a property of the HANDLE (options) -- never of B: a ragged tail, a short shard and a
+// one-frame call run the same per-output sums as a chip-filling micro-batch (launch_conv then picks, per layer, from (H, W)
+// alone whether the map tiles for k_conv_wino).  Round 2 chose per micro-batch and a frame's area depended on its neighbours.
+void pick_chain_form(og_unet* h, int /*B*/, int /*H*/, int /*W*/) {
+    h->wino_chain = h->wino && h->precision == 0 && h->conv_impl == 2;
 }
 
 int run_chunk(og_unet* h, int kind, const void* in, int B, int H, int W, float thr, const int32_t* boxes, uint8_t* mask,
@@ -1253,7 +1259,11 @@ inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 extern "C" {
 
 const char* og_last_error(void) { return g_err.c_str(); }
-const char* og_version(void) { return "openglottal_hip 0.1 (gfx950)"; }
+// The string names the build's answer to the GFX9 store-data hazard (og_buffer_store16, profiles/r02_epilogue_fence_audit.md):
+// the Python loader refuses a library that does not say "store_nop=1" (an audit build with -DOG_STORE_NOP=0 computes wrong lanes).
+#define OG_STR2(x) #x
+#define OG_STR(x) OG_STR2(x)
+const char* og_version(void) { return "openglottal_hip 0.3 (gfx950; store_nop=" OG_STR(OG_STORE_NOP) ")"; }
 
 int og_device_count(void) {
     int n = 0;

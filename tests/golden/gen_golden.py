@@ -156,6 +156,133 @@ def gen_full128(UNet, unet_segment_frame, dice, iou, meta) -> None:
     print("full128: areas", areas[:4], areas[80:84], "near-zero pixels", len(near), "min|logit|", np.abs(flat).min())
 
 
+def gen_self_noise(UNet, meta) -> None:
+    """(8) How far apart are two runs of the REFERENCE ITSELF?  `UNet.forward` of section (7)'s net on the same 128 frames
+    under two other summation orders oneDNN offers on this machine -- one intra-op thread instead of eight, and the
+    channels_last memory format -- against the fixture's own logits (8 threads, NCHW).  Stored: per-frame max |dlogit| of
+    each variant and every pixel whose sign differs.  The parity tests take their flip band from these numbers (the largest
+    difference the reference shows against itself), not from a literal."""
+    import torch
+
+    from openglottal_amd import synth
+
+    g1 = np.load(os.path.join(HERE, "unet_full.npz"))
+    feats = tuple(int(f) for f in g1["features"])
+    sd = synth.make_unet_state_dict(feats, seed=int(g1["seed"]), head_scale=float(g1["head_scale"]), head_bias=float(g1["head_bias"]))
+    model = UNet(1, 1, feats)
+    model.load_state_dict(synth.state_dict_to_torch(sd))
+    model.eval()
+    frames, _ = synth.full128_frames()
+
+    def run(threads: int, channels_last: bool) -> np.ndarray:
+        torch.set_num_threads(threads)
+        m = model.to(memory_format=torch.channels_last) if channels_last else model.to(memory_format=torch.contiguous_format)
+        out = np.empty((128, 256, 256), np.float32)
+        with torch.no_grad():
+            for i in range(128):
+                x = torch.from_numpy(frames[i:i + 1].astype("float32") / 255.0).unsqueeze(1)
+                if channels_last:
+                    x = x.contiguous(memory_format=torch.channels_last)
+                out[i] = m(x).contiguous().numpy()[0, 0]
+        return out
+
+    base = run(8, False)
+    fx = np.load(os.path.join(HERE, "unet_full128.npz"))
+    assert np.array_equal(base.reshape(128, -1)[:, fx["sample_idx"]], fx["logits_samples"]), "8-thread NCHW run is not the fixture's"
+    out = {}
+    for name, (thr, cl) in {"threads1": (1, False), "channels_last": (8, True)}.items():
+        v = run(thr, cl)
+        d = np.abs(v - base).reshape(128, -1)
+        fl = np.argwhere((v > 0).reshape(128, -1) != (base > 0).reshape(128, -1))
+        out[f"{name}_max_abs_dlogit"] = d.max(axis=1).astype(np.float32)
+        out[f"{name}_flip_frame"] = fl[:, 0].astype(np.int32)
+        out[f"{name}_flip_pixel"] = fl[:, 1].astype(np.int32)
+        out[f"{name}_flip_base_logit"] = base.reshape(128, -1)[fl[:, 0], fl[:, 1]].astype(np.float32)
+        print(f"self-noise {name}: max |dlogit| {d.max():.3e}, sign flips {len(fl)} of {128 * 65536}")
+    torch.set_num_threads(8)
+    model.to(memory_format=torch.contiguous_format)
+    band = float(max(out["threads1_max_abs_dlogit"].max(), out["channels_last_max_abs_dlogit"].max()))
+    np.savez_compressed(os.path.join(HERE, "unet_full128_self_noise.npz"), band=np.float32(band), **out)
+    meta["unet_full128_self_noise"] = {"band_max_abs_dlogit": band,
+                                       "flips_threads1": int(len(out["threads1_flip_frame"])),
+                                       "flips_channels_last": int(len(out["channels_last_flip_frame"]))}
+
+
+def gen_trained_full(UNet, unet_segment_frame, dice, iou, dice_loss, meta, steps: int = 300) -> None:
+    """(9) FULL-WIDTH trained net: the reference's `UNet(1,1,(32,64,128,256))` trained here with the reference's recipe
+    (AdamW 1e-3, 0.5 BCE + 0.5 Dice, `scripts/train_unet.py:141,155-157`, `utils.py:209-213`) on the synthetic glottis
+    frames, every tensor then rounded to float16-representable values (weights are data; halves the file), and the ROUNDED
+    net evaluated by the reference's `unet_segment_frame` on the 80-frame GIRAFE stand-in: bit-packed masks, integer areas,
+    Dice/IoU vs GT, sampled logits, the smallest |logit| per frame.  A trained net has the margins a real checkpoint has,
+    so the GPU test compares masks and areas EXACTLY (no flip rule)."""
+    import time
+
+    import torch
+
+    from openglottal_amd import synth
+
+    feats = (32, 64, 128, 256)
+    torch.manual_seed(2)
+    tm = UNet(1, 1, feats)
+    opt = torch.optim.AdamW(tm.parameters(), lr=1e-3)
+    tr_x, tr_y = synth.glottis_frames(12, 20, seed=1001)
+    tx = torch.from_numpy(tr_x.astype("float32") / 255.0).unsqueeze(1)
+    ty = torch.from_numpy((tr_y > 0).astype("float32")).unsqueeze(1)
+    tm.train()
+    g = torch.Generator().manual_seed(4)
+    t0 = time.time()
+    for step in range(steps):
+        idx = torch.randint(0, tx.shape[0], (8,), generator=g)
+        lo = tm(tx[idx])
+        loss = 0.5 * torch.nn.functional.binary_cross_entropy_with_logits(lo, ty[idx]) + 0.5 * dice_loss(lo, ty[idx])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if step % 20 == 0:
+            print(f"  full-width train step {step} loss {float(loss):.4f} ({time.time() - t0:.0f} s)", flush=True)
+    tsd = {}
+    for k, v in tm.state_dict().items():
+        a = v.detach().numpy()
+        if k.endswith("num_batches_tracked"):
+            tsd[k] = a.astype(np.int64)
+            continue
+        h = a.astype(np.float16)
+        if k.endswith("running_var"):
+            h = np.maximum(h, np.float16(1e-4))   # keep the variance a normal positive half
+        tsd[k] = h
+    tm.load_state_dict({k: torch.from_numpy(v.astype(np.float32) if v.dtype == np.float16 else v) for k, v in tsd.items()})
+    tm.eval()
+    dev = torch.device("cpu")
+    ev_x, ev_y = synth.glottis_frames(4, 20, seed=99)   # the 80-frame GIRAFE stand-in
+    ev_masks = np.stack([unet_segment_frame(f, tm, dev) for f in ev_x])
+    ev_logits = np.empty((80, 256, 256), np.float32)
+    with torch.no_grad():
+        for i in range(80):
+            ev_logits[i] = tm(torch.from_numpy(ev_x[i:i + 1].astype("float32") / 255.0).unsqueeze(1)).numpy()[0, 0]
+    assert np.array_equal(ev_masks > 0, ev_logits > 0)
+    ev_areas = np.array([int(np.sum(m > 0)) for m in ev_masks], dtype=np.int64)
+    ev_dice = np.array([dice(m, g_) for m, g_ in zip(ev_masks, ev_y)])
+    ev_iou = np.array([iou(m, g_) for m, g_ in zip(ev_masks, ev_y)])
+    samp = np.random.RandomState(9).choice(256 * 256, size=1024, replace=False).astype(np.int32)
+    flat = ev_logits.reshape(80, -1)
+    near = np.argwhere(np.abs(flat) < 1e-3)
+    np.savez_compressed(
+        os.path.join(HERE, "unet_trained_full.npz"),
+        features=np.array(feats),
+        **{"W:" + k: v for k, v in tsd.items()},
+        masks_packed=np.stack([packbits(m) for m in ev_masks]),
+        areas=ev_areas, dice_vs_gt=ev_dice, iou_vs_gt=ev_iou,
+        sample_idx=samp, logits_samples=flat[:, samp].astype(np.float32),
+        abs_logit_min=np.abs(flat).min(axis=1),
+        near_zero_frame=near[:, 0].astype(np.int32), near_zero_pixel=near[:, 1].astype(np.int32),
+        near_zero_logit=flat[near[:, 0], near[:, 1]].astype(np.float32),
+    )
+    meta["trained_full"] = {"steps": steps, "mean_dice": float(ev_dice.mean()), "mean_iou": float(ev_iou.mean()),
+                            "abs_logit_min": float(np.abs(flat).min()), "n_abs_logit_lt_1e3": int(len(near)),
+                            "areas_first8": ev_areas[:8].tolist()}
+    print("trained full: mean dice", ev_dice.mean(), "areas", ev_areas[:10], "min|logit|", np.abs(flat).min(), "n<1e-3:", len(near))
+
+
 def main() -> None:
     install_placeholders()
     import torch
@@ -173,10 +300,19 @@ def main() -> None:
 
     dev = torch.device("cpu")
     meta: dict = {"torch": torch.__version__, "numpy": np.__version__, "threads": torch.get_num_threads()}
-    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "full128":
-        # regenerate section (7) alone; every other fixture (and the rest of meta.json) stays as committed
+    if "--only" in sys.argv:
+        # regenerate one of sections (7)-(9) alone; every other fixture (and the rest of meta.json) stays as committed
+        which = sys.argv[sys.argv.index("--only") + 1]
         meta = json.load(open(os.path.join(HERE, "meta.json")))
-        gen_full128(UNet, unet_segment_frame, dice, iou, meta)
+        if which == "full128":
+            gen_full128(UNet, unet_segment_frame, dice, iou, meta)
+        elif which == "self_noise":
+            gen_self_noise(UNet, meta)
+        elif which == "trained_full":
+            torch.set_num_threads(int(os.environ.get("OG_GEN_THREADS", "8")))
+            gen_trained_full(UNet, unet_segment_frame, dice, iou, dice_loss, meta, steps=int(os.environ.get("OG_GEN_STEPS", "300")))
+        else:
+            raise SystemExit(f"unknown section {which}")
         with open(os.path.join(HERE, "meta.json"), "w") as f:
             json.dump(meta, f, indent=1)
         return
@@ -387,6 +523,8 @@ def main() -> None:
 
     # ── (7) full width, 128 frames: C1 stand-in + the bench configuration's pin ──
     gen_full128(UNet, unet_segment_frame, dice, iou, meta)
+    gen_self_noise(UNet, meta)
+    gen_trained_full(UNet, unet_segment_frame, dice, iou, dice_loss, meta)
 
     with open(os.path.join(HERE, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1)

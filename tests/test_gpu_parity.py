@@ -160,8 +160,7 @@ def test_chunking_and_graphs_are_result_invariant(trained):
     g, sd, m, frames, gt = trained
     fr = frames[:37]  # ragged: not a multiple of any chunk below
     base = None
-    m.set_option("splitk", 0)  # split-K (small launches only) changes the summation order: covered by its own test
-    for chunk, graphs in [(16, True), (1, True), (5, False), (64, True), (16, False)]:
+    for chunk, graphs in [(16, True), (1, True), (5, False), (64, True), (16, False)]:   # default options: the canonical form
         m.set_chunk(chunk)
         m.set_graphs(graphs)
         masks, areas, logits = m.segment(fr, want_logits=True)
@@ -178,14 +177,17 @@ def test_chunking_and_graphs_are_result_invariant(trained):
     m.set_option("lanes", 0)
     m.set_chunk(32)
     m.set_graphs(True)
-    m.set_option("splitk", 1)
     assert np.array_equal(base[1].astype(np.int64), g["areas"][:37])
 
 
 def test_split_k_latency_mode(trained, full):
-    """Small launches (batch 1..4) split K over workgroups and reduce in a fixed order: deterministic,
-    within fp32 re-association noise of the unsplit path, and still bit-exact on the trained fixture."""
+    """OPT-IN latency mode ("splitk" 1 on the direct kernels, "wino" 0; off by default because it makes a frame's logits
+    depend on the size of its launch): small launches (batch 1..4) split K over workgroups and reduce in a fixed order:
+    deterministic, within fp32 re-association noise of the unsplit path, and still bit-exact on the trained fixture."""
     g, sd, m, frames, gt = trained
+    gf, sdf, mf, framesf, gtf = full
+    for mm in (m, mf):
+        mm.set_option("wino", 0)
     m.set_option("splitk", 1)
     for B in (1, 2, 3):
         m.set_chunk(B)
@@ -194,7 +196,6 @@ def test_split_k_latency_mode(trained, full):
         assert np.array_equal(logits, logits2) and np.array_equal(areas, areas2)      # deterministic
         assert np.array_equal(areas.astype(np.int64), g["areas"][:6])
         assert np.array_equal(masks > 0, np.stack([unpack(b) for b in g["masks_packed"][:6]]) > 0)
-    gf, sdf, mf, framesf, gtf = full
     mf.set_chunk(1)
     mf.set_option("splitk", 1)
     _, a1, l1 = mf.segment(framesf, want_mask=False, want_logits=True)
@@ -203,6 +204,8 @@ def test_split_k_latency_mode(trained, full):
     mf.set_option("splitk", 1)
     mf.set_chunk(32)
     m.set_chunk(32)
+    m.set_option("splitk", 0)
+    m.set_option("wino", 1)
     assert not np.array_equal(l0, l1)                                                 # the split path really ran
     assert np.abs(l0 - l1).max() <= TOL
     # fused reduce (last-arriving K part sums all parts in split order) == separate reduce kernel, bit for bit, every time
@@ -226,16 +229,18 @@ def test_split_k_latency_mode(trained, full):
     mf.set_option("splitk_nt1", 1)
     mf.set_option("splitk_min_steps", 3)
     mf.set_chunk(32)
+    mf.set_option("splitk", 0)
+    mf.set_option("wino", 1)
     assert np.abs(l1.reshape(8, -1)[:, gf["sample_idx"]] - gf["logits_samples"]).max() <= TOL
     assert np.all(np.abs(a0.astype(int) - a1.astype(int)) <= ((l0 > 0) != (l1 > 0)).reshape(8, -1).sum(1))
 
 
 def test_kernel_variants_bit_identical(full):
-    """One-tile-per-workgroup kernel vs persistent pipelined kernel, all tap-group sizes: same
-    accumulation order per output element -> bit-identical logits."""
+    """The DIRECT form ("wino" 0): one-tile-per-workgroup kernel vs persistent pipelined kernel vs occupancy kernel, all
+    tap-group sizes: same accumulation order per output element -> bit-identical logits."""
     g, sd, m, frames, gt = full
     fr = frames[:5]
-    m.set_option("splitk", 0)
+    m.set_option("wino", 0)
     m.set_option("conv_impl", 0)
     _, a0, l0 = m.segment(fr, want_mask=False, want_logits=True)
     try:
@@ -267,7 +272,7 @@ def test_kernel_variants_bit_identical(full):
         m.set_option("tps_nt1", 3)
         m.set_option("tps_nt2", 1)
         m.set_option("wg_per_cu", 2)
-        m.set_option("splitk", 1)
+        m.set_option("wino", 1)
 
 
 def test_empty_batch_and_bad_shapes(trained):
@@ -505,8 +510,8 @@ def test_occupancy_kernels_on_partial_tiles_large_batch():
                                            ((40, 80), (64, 64), 128),        # padded channel slots (40 -> 64 columns; 80 -> 96 and 160: 32-column tiles)
                                            ((32, 64), (512, 512), 4)])      # large frames: a micro-batch of 4 fills the chip
 def test_winograd_form_against_oracle_and_direct_form(feats, shape, B):
-    """Every micro-batch that fills the chip runs its 3x3 convs in Winograd F(2x2,3x3) form (k_conv_wino<2> on 16x16-pixel
-    tiles, k_conv_wino<1> on 32x16 ones), layer by layer where the map tiles, the direct kernels elsewhere -- against the
+    """The canonical form: every 3x3 conv whose map tiles runs in Winograd F(2x2,3x3) form (k_conv_wino<2> on 16x16-pixel
+    tiles, k_conv_wino<1> on 32x16 ones) at EVERY micro-batch size, the direct kernels on the other layers -- against the
     oracle at the usual tolerance, against the direct form of the same chain, deterministic, and with the kernels asserted."""
     import torch
     from oracle import unet_oracle as O
@@ -532,8 +537,10 @@ def test_winograd_form_against_oracle_and_direct_form(feats, shape, B):
     diff = (masks[:n_ref] > 0) != (ref_mask > 0)
     assert np.all(np.abs(ref_logits[diff]) <= TOL * scale)
     assert np.array_equal(areas, (masks > 0).reshape(B, -1).sum(1))
-    # half the micro-batch (below the threshold for most of these shapes: direct kernels whatever the option says)
+    # the form is a property of the handle, not of the micro-batch: half the batch, and one frame per chain, bit for bit
     m.set_option("wino", 1)
-    m.set_chunk(max(1, B // 2))
-    _, _, logits_h = m.segment(fr[: max(1, B // 2)], want_logits=True)
-    assert np.abs(logits_h - logits_d[: max(1, B // 2)]).max() <= TOL * scale
+    for ch in (max(1, B // 2), 1):
+        m.set_chunk(ch)
+        n = min(B, max(ch, 3))
+        _, areas_h, logits_h = m.segment(fr[:n], want_logits=True)
+        assert np.array_equal(logits_h, logits[:n]) and np.array_equal(areas_h, areas[:n]), ch

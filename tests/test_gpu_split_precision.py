@@ -190,15 +190,16 @@ def test_randomised_entry_point_matrix_both_precisions():
 
 
 def test_latency_mode_split_k_in_split_precision(golden_dir):
-    """One frame per kernel chain at full width: the split-precision kernels split K across workgroups like the f32 ones
-    (fused reduce by the last-arriving part, parts summed in split order): deterministic, and within tolerance of the
-    reference fixture."""
+    """One frame per kernel chain at full width with the opt-in "splitk" 1: the split-precision kernels split K across
+    workgroups like the f32 ones (fused reduce by the last-arriving part, parts summed in split order): deterministic, and
+    within tolerance of the reference fixture."""
     g = np.load(os.path.join(golden_dir, "unet_full128.npz"))
     feats = tuple(int(f) for f in g["features"])
     sd = synth.make_unet_state_dict(feats, seed=int(g["seed"]), head_scale=float(g["head_scale"]), head_bias=float(g["head_bias"]))
     m = make_model(sd, feats)
     frames, gt = synth.full128_frames()
     nz = {(int(f), int(p)): float(v) for f, p, v in zip(g["near_zero_frame"], g["near_zero_pixel"], g["near_zero_logit"])}
+    m.set_option("splitk", 1)
     for chunk in (1, 2):
         m.set_chunk(chunk)
         mk, ar, lg = m.segment(frames[:12], want_logits=True)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Reproduce the audit of profiles/r02_epilogue_fence_audit.md (the store-data hazard behind round 1's "fence").
 #   tools/epilogue_fence_audit.sh isa     # CPU: hazard scan of the shipped ISA and of the build without the wait state
-#   tools/epilogue_fence_audit.sh build   # CPU: libopenglottal_hip_nonop.so = the library WITHOUT the wait state (-DOG_STORE_NOP=0)
+#   tools/epilogue_fence_audit.sh build   # CPU: gpurun_out/libopenglottal_hip_nonop.so = the library WITHOUT the wait state (-DOG_STORE_NOP=0)
 #   tools/epilogue_fence_audit.sh probe   # GPU box: one correctness probe of each (tools/store_hazard_probe.py)
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
@@ -16,11 +16,11 @@ isa)
     echo "== -DOG_STORE_NOP=0"; python3 "$HERE/tools/isa_store_hazard.py" "$T/nonop.s" || true
     ;;
 build)
-    bash "$HERE/openglottal_amd/csrc/build.sh" -DOG_STORE_NOP=0 -o "$HERE/openglottal_amd/libopenglottal_hip_nonop.so" > /dev/null 2>&1
-    ls -la "$HERE"/openglottal_amd/libopenglottal_hip_nonop.so
+    bash "$HERE/openglottal_amd/csrc/build.sh" -DOG_STORE_NOP=0 -o "$HERE/gpurun_out/libopenglottal_hip_nonop.so" > /dev/null 2>&1
+    ls -la "$HERE"/gpurun_out/libopenglottal_hip_nonop.so
     ;;
 probe)
-    OPENGLOTTAL_HIP_LIB="$HERE/openglottal_amd/libopenglottal_hip_nonop.so" timeout -k 10 120 python3 "$HERE/tools/store_hazard_probe.py" 2>&1 | grep -v amdgpu.ids || true
+    OPENGLOTTAL_HIP_ALLOW_AUDIT_BUILD=1 OPENGLOTTAL_HIP_LIB="$HERE/gpurun_out/libopenglottal_hip_nonop.so" timeout -k 10 120 python3 "$HERE/tools/store_hazard_probe.py" 2>&1 | grep -v amdgpu.ids || true
     timeout -k 10 120 python3 "$HERE/tools/store_hazard_probe.py" 2>&1 | grep -v amdgpu.ids
     ;;
 esac
