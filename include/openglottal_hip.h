@@ -95,6 +95,12 @@ int og_unet_segment_u8(og_unet* h, const uint8_t* gray, int B, int H, int W, flo
  * boxes / mask / area as og_unet_segment_u8.  og_unet_segment_u8 itself runs on this engine (option "stream" 0: one-shot). */
 int og_unet_stream_u8(og_unet* h, const uint8_t* frames, int B, int H, int W, int channels, float threshold,
                       const int32_t* boxes, uint8_t* mask, int32_t* area);
+/* The same engine for a video held the way the reference holds it: a LIST of separately allocated frames (`frames_bgr`,
+ * utils.py:43-54 / features.py:226,234).  frame_ptrs[i] -> frame i, [H,W] gray or [H,W,3] BGR u8, contiguous.  Each frame is
+ * copied ONCE, straight into the pinned ring slot of its micro-batch, while the device works on the micro-batches before it:
+ * no stacked copy of the video is ever made (a Python np.stack of 502 frames costs more than a fifth of the whole pass). */
+int og_unet_stream_frames_u8(og_unet* h, const uint8_t* const* frame_ptrs, int B, int H, int W, int channels, float threshold,
+                             const int32_t* boxes, uint8_t* mask, int32_t* area);
 /* Same as og_unet_segment_u8, DEVICE pointers, asynchronous on the handle's stream. */
 int og_unet_segment_u8_dev(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, float threshold,
                            const int32_t* boxes_dev, uint8_t* mask_dev, int32_t* area_dev, float* logits_dev);

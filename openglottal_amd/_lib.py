@@ -43,6 +43,8 @@ PROTOTYPES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "og_unet_stream_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "og_unet_stream_frames_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "og_unet_segment_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "og_unet_segment_crops_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,

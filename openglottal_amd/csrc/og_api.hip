@@ -1663,13 +1663,16 @@ int og_unet_segment_u8_dev(og_unet* h, const uint8_t* gray, int B, int H, int W,
 }
 
 // The frame loop with the video on the HOST (features.py:226,234-245), streamed: see og_unet::Ring.
-static int stream_impl(og_unet* h, const uint8_t* frames, int B, int H, int W, int ch, float thr, const int32_t* boxes, uint8_t* mask,
-                       int32_t* area, float* logits) {
+static int stream_impl(og_unet* h, const uint8_t* frames, const uint8_t* const* frame_ptrs, int B, int H, int W, int ch, float thr,
+                       const int32_t* boxes, uint8_t* mask, int32_t* area, float* logits) {
     int rc = check_shape(h, B, H, W);
     if (rc) return rc;
     if (ch != 1 && ch != 3) return fail(OG_EINVAL, "channels must be 1 (gray) or 3 (BGR)");
     if (B == 0) return OG_OK;
-    if (!frames) return fail(OG_EINVAL, "frames is null");
+    if (!frames && !frame_ptrs) return fail(OG_EINVAL, "frames is null");
+    if (frame_ptrs)
+        for (int i = 0; i < B; ++i)
+            if (!frame_ptrs[i]) return fail(OG_EINVAL, "frame_ptrs[" + std::to_string(i) + "] is null");
     const int chunk = effective_chunk(h);
     const int cb = chunk < B ? chunk : B;
     const int n_chunks = (B + chunk - 1) / chunk;
@@ -1684,7 +1687,7 @@ static int stream_impl(og_unet* h, const uint8_t* frames, int B, int H, int W, i
     if ((rc = ensure_ring(h, n_slots, cb, H, W, ch, mask != nullptr, logits != nullptr))) return rc;
     auto& R = h->ring;
     const size_t HW = (size_t)H * W, fb = HW * ch;
-    const bool pinned = is_pinned_host(frames);
+    const bool pinned = frames != nullptr && is_pinned_host(frames);
     const bool single = n_chunks == 1;
 
     auto retire = [&](og_unet::Slot& s) -> int {   // wait for the slot's outputs and hand them to the caller
@@ -1698,8 +1701,11 @@ static int stream_impl(og_unet* h, const uint8_t* frames, int B, int H, int W, i
         return OG_OK;
     };
     auto fill = [&](og_unet::Slot& s, og_unet* lane, int b0, int nb) -> int {
-        const uint8_t* src = frames + (size_t)b0 * fb;
-        if (!pinned) {   // pageable memory: stage through the slot's pinned buffer so that the DMA is asynchronous
+        const uint8_t* src = frames ? frames + (size_t)b0 * fb : nullptr;
+        if (frame_ptrs) {   // a list of separately allocated frames: gathered here, one copy per frame, into the pinned slot
+            for (int j = 0; j < nb; ++j) memcpy(s.h_in + (size_t)j * fb, frame_ptrs[b0 + j], fb);
+            src = s.h_in;
+        } else if (!pinned) {   // pageable memory: stage through the slot's pinned buffer so that the DMA is asynchronous
             memcpy(s.h_in, src, nb * fb);
             src = s.h_in;
         }
@@ -1762,12 +1768,18 @@ static int stream_impl(og_unet* h, const uint8_t* frames, int B, int H, int W, i
 
 int og_unet_stream_u8(og_unet* h, const uint8_t* frames, int B, int H, int W, int channels, float thr, const int32_t* boxes,
                       uint8_t* mask, int32_t* area) {
-    return stream_impl(h, frames, B, H, W, channels, thr, boxes, mask, area, nullptr);
+    return stream_impl(h, frames, nullptr, B, H, W, channels, thr, boxes, mask, area, nullptr);
+}
+
+int og_unet_stream_frames_u8(og_unet* h, const uint8_t* const* frame_ptrs, int B, int H, int W, int channels, float thr,
+                             const int32_t* boxes, uint8_t* mask, int32_t* area) {
+    if (!frame_ptrs && B > 0) return fail(OG_EINVAL, "frame_ptrs is null");
+    return stream_impl(h, nullptr, frame_ptrs, B, H, W, channels, thr, boxes, mask, area, nullptr);
 }
 
 int og_unet_segment_u8(og_unet* h, const uint8_t* gray, int B, int H, int W, float thr, const int32_t* boxes,
                        uint8_t* mask, int32_t* area, float* logits) {
-    if (h && h->stream_host) return stream_impl(h, gray, B, H, W, 1, thr, boxes, mask, area, logits);
+    if (h && h->stream_host) return stream_impl(h, gray, nullptr, B, H, W, 1, thr, boxes, mask, area, logits);
     // one-shot staging of the whole batch ("stream" option 0; kept as the reference the streaming path is tested against)
     int rc = check_shape(h, B, H, W);
     if (rc) return rc;

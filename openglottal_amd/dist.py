@@ -106,7 +106,7 @@ def sharded_gated_area_waveform(frames_bgr, detect_batch, make_detector, model, 
     """
     import torch
 
-    from .utils import bgr_to_gray, normalize_box
+    from .utils import normalize_box
 
     n = len(frames_bgr)
     lo, hi = shard_range(n, rank, world)
@@ -124,8 +124,9 @@ def sharded_gated_area_waveform(frames_bgr, detect_batch, make_detector, model, 
         b = det.update(best[i:i + 1, :4], best[i:i + 1, 4], W, H) if best[i, 4] >= 0 else det.update(None, None, W, H)
         boxes[i] = normalize_box(b, W, H)
     if hi > lo:
-        gray = np.stack([bgr_to_gray(f) for f in mine])
-        _, area, _ = model.segment(gray, boxes=boxes[lo:hi], want_mask=False)
+        # exactly what the single-process `area_waveform` does with a block: BGR frames + boxes to the streaming engine
+        # (BGR->gray of features.py:235 on the device, same kernels, same form)
+        _, area = model.segment_stream(mine, boxes=boxes[lo:hi])
     else:
         area = np.zeros(0, np.int32)
     ta = torch.from_numpy(np.ascontiguousarray(area))

@@ -145,8 +145,9 @@ def area_waveform(frames, detector, model, device=None, threshold: float = 0.5) 
         boxes = _detect_block(blk, detector) if detector is not None else None
         shapes = {f.shape for f in blk}
         if len(shapes) == 1 and next(iter(shapes))[:2] == (NET_SIZE, NET_SIZE):
-            arr = blk if isinstance(blk, np.ndarray) else np.stack(blk)
-            _, area = model.segment_stream(arr, threshold=threshold, boxes=boxes)
+            # an array goes up in place; a list of frames (features.py:226's `frames_bgr`) is gathered by the engine itself,
+            # frame by frame into its pinned ring -- no np.stack of the block
+            _, area = model.segment_stream(blk if isinstance(blk, np.ndarray) else list(blk), threshold=threshold, boxes=boxes)
             out.append(area.astype(np.float64))
         else:   # mixed / non-256 frames: per-frame path incl. host resizes (utils.py:234,239-240)
             a = np.zeros(n, np.float64)

@@ -136,6 +136,8 @@ class UNet:
         ``[B,H,W,3]`` BGR u8 (BGR→gray of features.py:235 on the device), numpy or a pinned torch tensor.  Device memory
         stays bounded by a few micro-batches however long the video is.  Returns ``(mask | None, area int32 [B])``."""
         self._require()
+        if isinstance(frames, (list, tuple)):    # the reference's `frames_bgr` list: no stacked copy, the engine gathers
+            return self._segment_frame_list(frames, threshold, boxes, want_mask)
         if hasattr(frames, "data_ptr"):          # torch CPU tensor (pinned or not): use its memory in place
             if frames.device.type != "cpu" or str(frames.dtype) != "torch.uint8" or not frames.is_contiguous():
                 raise OpenGlottalHipError("segment_stream expects a contiguous uint8 host tensor")
@@ -155,6 +157,27 @@ class UNet:
         bx = None if boxes is None else np.ascontiguousarray(boxes, dtype=np.int32).reshape(B, 4)
         check(lib().og_unet_stream_u8(self._h, ptr(f), B, H, W, ch, float(threshold), ptr(bx), ptr(mask), ptr(area)),
               "og_unet_stream_u8")
+        return mask, area
+
+    def _segment_frame_list(self, frames, threshold, boxes, want_mask):
+        """``og_unet_stream_frames_u8``: a list of separately allocated ``[H,W]`` / ``[H,W,3]`` u8 frames of one shape; each
+        frame is copied once, by the engine, into the pinned slot of its micro-batch (no ``np.stack``)."""
+        B = len(frames)
+        if B == 0:
+            return (np.empty((0, 0, 0), np.uint8) if want_mask else None), np.zeros(0, np.int32)
+        keep = [f if (isinstance(f, np.ndarray) and f.dtype == np.uint8 and f.flags.c_contiguous) else np.ascontiguousarray(f, dtype=np.uint8)
+                for f in frames]
+        shape = keep[0].shape
+        if any(f.shape != shape for f in keep) or len(shape) not in (2, 3) or (len(shape) == 3 and shape[2] != 3):
+            raise OpenGlottalHipError("segment_stream(list): frames must share one [H,W] or [H,W,3] shape")
+        H, W = shape[:2]
+        ch = 3 if len(shape) == 3 else 1
+        ptrs = (C.c_void_p * B)(*[f.ctypes.data for f in keep])
+        mask = np.empty((B, H, W), np.uint8) if want_mask else None
+        area = np.zeros(B, np.int32)
+        bx = None if boxes is None else np.ascontiguousarray(boxes, dtype=np.int32).reshape(B, 4)
+        check(lib().og_unet_stream_frames_u8(self._h, ptrs, B, H, W, ch, float(threshold), ptr(bx), ptr(mask), ptr(area)),
+              "og_unet_stream_frames_u8")
         return mask, area
 
     def segment_dev(self, gray_dev, B: int, H: int, W: int, area_dev, threshold: float = 0.5, boxes_dev=None,

@@ -1,24 +1,26 @@
 #!/usr/bin/env python3
-"""Counterpart of the reference's `scripts/benchmark_video_speed.py` with the SAME command line.
+"""Frames-per-second of the glottal-area frame loop on MI355X, two ways over the same frames.
 
-It times two things over the same frames (seeded `RandomState(1234+i)` instead of the reference's unseeded randint, or a
-`.npy` / `.npz` / image-directory video):
+Command line compatible with the reference harness of the same name (same flag names), implementation
+written against THIS package:
 
-  1. the reference's loop VERBATIM (benchmark_video_speed.py:89-101) with only the imports swapped — one
-     `cvtColor` + `unet_segment_frame(gray, model, device)` (+ `detector.detect(frame)`) per frame, host arrays in and out;
-  2. the same work as ONE call of `area_waveform` (what `extract_features_unet` does in this package): frames streamed to the
-     device in micro-batches, BGR→gray on the device, detector network batched, areas back.
+  per-frame   one `unet_segment_frame` call (and, with --yolo-weights, one `TemporalDetector.detect` call) per frame with
+              host arrays in and out -- the call pattern of the reference's frame loop (features.py:234-245)
+  streamed    the whole video in one `area_waveform` call: frames go to the device in micro-batches, BGR->gray, U-Net,
+              threshold and area count happen there, the detector network runs batched, only the areas come back
 
-Weights: a torch state_dict file (`--unet-weights`, loaded with `weights_only=True`) and a flat `.npz` export (`--yolo-weights`,
-see openglottal_amd/yolo.py); when a path does not exist the seeded synthetic weights of the test-suite are used and said so
-(the reference's weight files are not part of its repository snapshot).
+Both passes use the same arithmetic (the canonical form of DESIGN.md §4), so their area waveforms must be identical; the
+script checks that and reports it.  Frames are the seeded stream `RandomState(1234 + i)` of SURVEY §8(d), or a
+`.npy` / `.npz` / image-directory video given with --video.  Weight files that do not exist are replaced by the seeded
+synthetic weights of the test-suite, and the output says so (the reference's snapshot ships no weights).
 
-  python scripts/benchmark_video_speed.py --frames 502 --device cuda
-  python scripts/benchmark_video_speed.py --frames 502 --device cuda --yolo-weights weights/openglottal_yolo.npz
+  python scripts/benchmark_video_speed.py --frames 502
+  python scripts/benchmark_video_speed.py --frames 502 --yolo-weights weights/openglottal_yolo.npz
 """
 from __future__ import annotations
 
 import argparse
+import json
 import os
 import sys
 import time
@@ -27,101 +29,130 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+WIDTHS = (32, 64, 128, 256)
+PAPER_FPS = 502 / 11.0   # the reference's published claim: a 502-frame video in about 11 s on Apple MPS
 
-def main() -> None:
-    p = argparse.ArgumentParser(description="Benchmark U-Net video processing speed (MI355X path).")
-    p.add_argument("--frames", type=int, default=502, help="Number of frames to simulate (default: 502, GIRAFE median).")
-    p.add_argument("--device", type=str, default="cuda", help="Device: cuda or cuda:N (there is no CPU / MPS path).")
-    p.add_argument("--unet-weights", type=str, default="weights/openglottal_unet.pt", help="Path to U-Net weights.")
-    p.add_argument("--yolo-weights", type=str, default=None, help="If set, run YOLO+UNet (slower); else U-Net only.")
-    p.add_argument("--warmup", type=int, default=20, help="Warmup frames before timing.")
-    p.add_argument("--video", type=str, default=None, help="Optional: .npy/.npz/frame directory to use real frames and include load time.")
-    args = p.parse_args()
 
+def parse_args() -> argparse.Namespace:
+    ap = argparse.ArgumentParser(description="Time the U-Net (optionally YOLO-gated) area-waveform loop on an MI355X.")
+    ap.add_argument("--frames", type=int, default=502, help="how many frames to process (502 = a median GIRAFE recording)")
+    ap.add_argument("--device", default="cuda", help="'cuda' or 'cuda:N'; this package has no CPU or MPS path")
+    ap.add_argument("--unet-weights", default="weights/openglottal_unet.pt", help="torch state_dict of the U-Net (weights_only load)")
+    ap.add_argument("--yolo-weights", default=None, help="flat .npz export of the YOLOv8n detector; enables the detection-gated pipeline")
+    ap.add_argument("--warmup", type=int, default=20, help="frames pushed through both passes before the clock starts")
+    ap.add_argument("--video", default=None, help=".npy / .npz / directory of images to read frames from (read time reported separately)")
+    ap.add_argument("--json", action="store_true", help="also print the numbers as one JSON line")
+    return ap.parse_args()
+
+
+def build_unet(path: str, device: str):
     import torch
 
-    from openglottal_amd import TemporalDetector, UNet, synth
-    from openglottal_amd.features import area_waveform, load_frames_bgr
-    from openglottal_amd.utils import bgr_to_gray, unet_segment_frame
+    from openglottal_amd import UNet, synth
+
+    net = UNet(1, 1, WIDTHS).to(device)
+    if os.path.exists(path):
+        net.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+        origin = path
+    else:
+        net.load_state_dict(synth.make_unet_state_dict(WIDTHS, seed=20260227, head_scale=3.4732823371887207, head_bias=-2.890756130218506))
+        origin = f"seeded synthetic weights ({path} does not exist)"
+    return net.eval(), origin
+
+
+def build_detector(path: str | None, device: str):
+    if not path:
+        return None, None
+    from openglottal_amd import TemporalDetector, synth
     from openglottal_amd.yolo import YoloV8Detector
 
-    device = args.device
-    feats = (32, 64, 128, 256)
-    model = UNet(1, 1, feats).to(device)
-    if os.path.exists(args.unet_weights):
-        model.load_state_dict(torch.load(args.unet_weights, map_location="cpu", weights_only=True))
-    else:
-        print(f"Note: {args.unet_weights} not found — seeded synthetic U-Net weights (tests/golden calibration)")
-        model.load_state_dict(synth.make_unet_state_dict(feats, seed=20260227, head_scale=3.4732823371887207, head_bias=-2.890756130218506))
-    model.eval()
+    if os.path.exists(path):
+        return TemporalDetector(path), path
+    backend = YoloV8Detector(synth.make_yolov8_state_dict(seed=7, cls_bias=1.0), device=device)
+    return TemporalDetector(backend), f"random-init YOLOv8n ({path} does not exist)"
 
-    detector = None
-    if args.yolo_weights:
-        if os.path.exists(args.yolo_weights):
-            detector = TemporalDetector(args.yolo_weights)
-        else:
-            print(f"Note: {args.yolo_weights} not found — random-init YOLOv8n weights")
-            detector = TemporalDetector(YoloV8Detector(synth.make_yolov8_state_dict(seed=7, cls_bias=1.0), device=device))
-        print("Pipeline: YOLO+UNet (detection-gated)")
-    else:
-        print("Pipeline: U-Net only")
 
-    if args.video:
-        t0 = time.perf_counter()
-        frames_bgr = load_frames_bgr(args.video)
-        load_s = time.perf_counter() - t0
-        n_frames = min(len(frames_bgr), args.frames)
-        frames_bgr = frames_bgr[:n_frames]
-        print(f"Loaded {n_frames} frames from {args.video} in {load_s:.2f} s")
-    else:
-        n_frames = args.frames
-        frames_bgr = [synth.bench_frame_bgr(i) for i in range(n_frames)]
-        load_s = 0.0
-        print(f"Using {n_frames} synthetic 256×256 frames, RandomState(1234+i) (no load time)")
+def frame_source(video: str | None, count: int):
+    """(list of BGR frames, seconds spent reading them, description)."""
+    from openglottal_amd import synth
+    from openglottal_amd.features import load_frames_bgr
 
-    if detector:
+    if video is None:
+        return [synth.bench_frame_bgr(i) for i in range(count)], 0.0, f"{count} seeded 256x256 BGR frames, RandomState(1234+i)"
+    t = time.perf_counter()
+    frames = load_frames_bgr(video)[:count]
+    return frames, time.perf_counter() - t, f"{len(frames)} frames of {video}"
+
+
+def per_frame_pass(frames, net, detector, device) -> np.ndarray:
+    """One device round trip per frame, as the reference does it."""
+    from openglottal_amd.utils import bgr_to_gray, unet_segment_frame
+
+    wave = np.zeros(len(frames))
+    if detector is not None:
         detector.reset()
-    for frm in frames_bgr[: args.warmup]:
-        unet_segment_frame(bgr_to_gray(frm), model, device)
-        if detector is not None:
-            detector.detect(frm)
-    torch.cuda.synchronize()
-
-    # 1. timed run, the reference's loop body with the imports swapped (benchmark_video_speed.py:89-101)
-    areas_loop = []
-    t0 = time.perf_counter()
-    for frm_bgr in frames_bgr:
-        gray_full = bgr_to_gray(frm_bgr)
-        mask_full = unet_segment_frame(gray_full, model, device)
+    for i, frame in enumerate(frames):
+        mask = unet_segment_frame(bgr_to_gray(frame), net, device)
         if detector is None:
-            areas_loop.append(float(np.sum(mask_full > 0)))
-        else:
-            box = detector.detect(frm_bgr)
-            if box is None:
-                areas_loop.append(0.0)
-            else:
-                x1, y1, x2, y2 = box
-                areas_loop.append(float(np.sum(mask_full[y1:y2, x1:x2] > 0)))
+            wave[i] = np.count_nonzero(mask)
+            continue
+        hit = detector.detect(frame)
+        if hit is not None:
+            left, top, right, bottom = hit
+            wave[i] = np.count_nonzero(mask[top:bottom, left:right])
+    return wave
+
+
+def streamed_pass(frames, net, detector, device) -> np.ndarray:
+    from openglottal_amd.features import area_waveform
+
+    return area_waveform(frames, detector, net, device)
+
+
+def timed(fn, *a):
+    import torch
+
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    fps = n_frames / elapsed
+    t = time.perf_counter()
+    out = fn(*a)
+    torch.cuda.synchronize()
+    return out, time.perf_counter() - t
 
-    # 2. the same frames through the batched frame loop (extract_features_unet's path in this package)
-    area_waveform(frames_bgr[: max(args.warmup, 64)], detector, model, device)
-    t0 = time.perf_counter()
-    wave = area_waveform(frames_bgr, detector, model, device)
-    elapsed_b = time.perf_counter() - t0
-    d = np.abs(np.asarray(areas_loop) - wave)
 
-    print(f"\nResults ({n_frames} frames, device={device}):")
-    print(f"  Per-frame loop (reference call pattern): {elapsed:.3f} s  →  {fps:.1f} frames/s")
-    print(f"  Batched frame loop (area_waveform):      {elapsed_b:.3f} s  →  {n_frames / elapsed_b:.1f} frames/s")
-    print(f"  Areas of the two runs: identical on {int((d == 0).sum())} of {n_frames} frames, max |difference| {int(d.max())} px "
-          "(one frame per launch splits K across workgroups: sums re-associate in the last bits, which moves pixels whose logit is ~0)")
-    if load_s > 0:
-        print(f"  Video load time: {load_s:.2f} s")
-    print("\nPaper claim: 502 frames in ~11 s (~47 frames/s) on MPS.")
-    print(f"  Per-frame loop: {fps:.1f} fps  →  502 frames in {502 / fps:.2f} s  {'✓ within claim' if fps >= 502 / 11.0 else '✗'}")
+def main() -> None:
+    args = parse_args()
+    net, unet_origin = build_unet(args.unet_weights, args.device)
+    detector, det_origin = build_detector(args.yolo_weights, args.device)
+    frames, read_s, what = frame_source(args.video, args.frames)
+    n = len(frames)
+    if n == 0:
+        raise SystemExit("no frames to process")
+    print(f"pipeline : {'YOLO + U-Net, area counted inside the tracked box' if detector else 'U-Net only'}")
+    print(f"U-Net    : {unet_origin}")
+    if detector:
+        print(f"detector : {det_origin}")
+    print(f"frames   : {what}" + (f" (read in {read_s:.2f} s)" if read_s else ""))
+
+    head = frames[:max(1, min(n, args.warmup))]
+    per_frame_pass(head, net, detector, args.device)
+    streamed_pass(frames[:max(len(head), min(n, 128))], net, detector, args.device)   # also sizes the pinned ring and captures the graphs
+
+    loop_wave, loop_s = timed(per_frame_pass, frames, net, detector, args.device)
+    stream_wave, stream_s = timed(streamed_pass, frames, net, detector, args.device)
+    same = int(np.count_nonzero(loop_wave == stream_wave))
+
+    res = {"frames": n, "pipeline": "yolo+unet" if detector else "unet-only",
+           "per_frame_fps": round(n / loop_s, 1), "per_frame_ms_per_frame": round(1e3 * loop_s / n, 3),
+           "streamed_fps": round(n / stream_s, 1), "identical_areas": same,
+           "max_area_difference_px": int(np.abs(loop_wave - stream_wave).max()), "read_s": round(read_s, 3)}
+    print(f"\nper-frame calls : {loop_s:8.3f} s  = {res['per_frame_fps']:9.1f} frames/s  ({res['per_frame_ms_per_frame']} ms per frame)")
+    print(f"streamed video  : {stream_s:8.3f} s  = {res['streamed_fps']:9.1f} frames/s")
+    print(f"area waveforms  : {same} of {n} frames identical, largest difference {res['max_area_difference_px']} px")
+    verdict = "faster than" if res["per_frame_fps"] >= PAPER_FPS else "SLOWER than"
+    print(f"published figure: {PAPER_FPS:.1f} frames/s (502 frames in ~11 s, Apple MPS); the per-frame pass here is {verdict} it "
+          f"({502 / res['per_frame_fps']:.2f} s for 502 frames)")
+    if args.json:
+        print(json.dumps(res))
 
 
 if __name__ == "__main__":

@@ -59,7 +59,7 @@ def test_single_process_passthrough():
 
 
 class _FakeModel:
-    """Stand-in for UNet.segment on CPU: 'area' = number of pixels of a fixed pattern inside the box."""
+    """Stand-in for UNet.segment / UNet.segment_stream on CPU: 'area' = number of pixels of a fixed pattern inside the box."""
 
     def segment(self, gray, boxes=None, want_mask=False, **kw):
         out = np.zeros(len(gray), np.int32)
@@ -67,6 +67,9 @@ class _FakeModel:
             if b[0] >= 0:
                 out[i] = int((g[b[1]:b[3], b[0]:b[2]] > 100).sum())
         return None, out, None
+
+    def segment_stream(self, frames, threshold=0.5, boxes=None, want_mask=False):   # BGR in, as the streaming engine takes it
+        return None, self.segment([f[..., 1] for f in frames], boxes=boxes)[1]
 
 
 def _fake_detect(frames, conf):

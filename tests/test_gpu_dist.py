@@ -34,6 +34,20 @@ def _video():
     return gray, bgr
 
 
+def _record_route(m):
+    """Which engine entry a frame loop takes: [(method, input shape tail, boxes given)] per call into the model."""
+    route = []
+    for name in ("segment", "segment_stream"):
+        orig = getattr(m, name)
+
+        def wrapped(x, *a, _orig=orig, _name=name, **k):
+            route.append((_name, int(np.asarray(x[0]).ndim), k.get("boxes") is not None))
+            return _orig(x, *a, **k)
+
+        setattr(m, name, wrapped)
+    return route
+
+
 def _rank(rank, world, port, q):
     import torch.distributed as dist
 
@@ -45,8 +59,9 @@ def _rank(rank, world, port, q):
     gray, bgr = _video()
     plain = sharded_area_waveform(gray, m, rank, world)
     y = YoloV8Detector(synth.make_yolov8_state_dict(seed=7, cls_bias=1.0), device="cuda:0")
+    route = _record_route(m)
     gated, boxes = sharded_gated_area_waveform(list(bgr), y.detect_frames, lambda: og.TemporalDetector(y), m, rank, world)
-    q.put((rank, plain.tolist(), gated.tolist(), boxes.tolist()))
+    q.put((rank, plain.tolist(), gated.tolist(), boxes.tolist(), route))
     dist.destroy_process_group()
 
 
@@ -61,8 +76,10 @@ def test_sharded_waveforms_equal_single_process(world):
     ref_plain = area_waveform(gray, None, m)
     assert np.array_equal(ref_plain.astype(np.int64), g["areas"][np.arange(N) % 80])     # = the reference's integers
     y = YoloV8Detector(synth.make_yolov8_state_dict(seed=7, cls_bias=1.0), device="cuda:0")
+    route1 = _record_route(m)
     ref_gated = area_waveform(list(bgr), og.TemporalDetector(y), m)
     assert (ref_gated > 0).any()
+    assert route1 == [("segment_stream", 3, True)], route1      # BGR frames + boxes into the streaming engine, one call
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -76,6 +93,7 @@ def test_sharded_waveforms_equal_single_process(world):
     for p in ps:
         p.join(120)
     assert sorted(r[0] for r in res) == list(range(world))
-    for rank, plain, gated, boxes in res:
+    for rank, plain, gated, boxes, route in res:
         assert plain == ref_plain.astype(np.int64).tolist(), rank
         assert gated == ref_gated.astype(np.int64).tolist(), rank
+        assert [tuple(r) for r in route] == route1, (rank, route)      # the sharded gated loop takes the single-process loop's route
