@@ -115,6 +115,8 @@ struct og_unet {
                          // Which layers take it is a function of the handle's options and of (H, W) alone -- never of the micro-batch
                          // size, the lane, the shard or the entry point -- so a frame's mask is a function of the frame only
                          // (features.py:234-238 has no cross-frame state either).  0: the direct kernels for every layer.
+    int wino_ps = 1;     // under-filled Winograd launches spread a tile's 16 positions over several workgroups (k_conv_wino_ps: bit-identical);
+                         // 0 off, 1 auto, 2 / 3 / 4 force PN = 4 / 2 / 1 on every launch that qualifies
     int wino_first = 1;  // Winograd chains: first layer unfused so that the second conv takes k_conv_wino<1>
     bool wino_chain = false;   // (pick_chain_form) wino && precision == 0 && conv_impl == 2
     int splitk_nt1 = 1;  // split 3x3 launches on 32-column tiles (twice the workgroups, half the MFMAs per K part)
@@ -566,6 +568,30 @@ int launch_conv_wino(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {  
     return OG_OK;
 }
 
+template <int NT, int PN>
+constexpr int wino_ps_lds() {
+    constexpr int KC = 8 * NT, raw_it = ((32 / NT + 2) * 18 * (KC / 4) + 255) / 256, up = 32 * NT * KC * 4, la = (PN <= 2) ? 3 : 2;
+    return la * raw_it * 4096 + 2 * PN * 4096 + (la + 1) * ((PN * up > 4096) ? PN * up : 4096);
+}
+
+// k_conv_wino_ps: the same tiles as k_conv_wino, 16 / PN workgroups per (tile, column tile); needs the split-K workspace
+// (raw accumulators: 256 KB per (tile, column tile)) and the arrival counters
+template <int NT, int PN>
+int launch_conv_wino_ps(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
+    ConvArgs a = a_in;   // (a.stamps: per-workgroup timeline of diagnostic runs, 4 x u64 for up to 1024 workgroups)
+    a.ksplit = 1;
+    const int frames = a.n_spatial / (a.tiles_x * a.tiles_y);
+    a.zdiv = n_ntiles;
+    a.frames = frames;
+    a.zgroup_shift = 0;
+    a.zrcp = 1.0f / (float)a.zdiv;
+    if ((long long)frames * a.zdiv * (16 / PN) > 65535) return fail(OG_EINVAL, "k_conv_wino_ps: grid.z");
+    constexpr int lds = wino_ps_lds<NT, PN>();
+    hipLaunchKernelGGL((k_conv_wino_ps<NT, PN>), dim3(a.tiles_x, a.tiles_y, frames * a.zdiv * (16 / PN)), dim3(256), lds, c.stream, a);
+    HIPCHK(hipGetLastError());
+    return OG_OK;
+}
+
 template <int NT, int MODE, int TH, int OCC, bool SQ = false>
 int launch_conv_h(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {   // split-precision twin of launch_conv_o (no split-K)
     constexpr int lds = conv_o_lds<NT, MODE, TH>();
@@ -642,6 +668,12 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 16>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino<2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds<2>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds<1>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_ps<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (wino_ps_lds<2, 1>())));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_ps<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (wino_ps_lds<2, 2>())));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_ps<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (wino_ps_lds<2, 4>())));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_ps<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (wino_ps_lds<1, 1>())));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_ps<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (wino_ps_lds<1, 2>())));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_ps<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (wino_ps_lds<1, 4>())));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 1, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 1, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 8>()));
@@ -829,6 +861,31 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
             a.tiles_y = in.H / (32 / L.NT);
             a.n_spatial = B * a.tiles_x * a.tiles_y;
             a.wpk = L.d_ww;
+            // A launch that leaves most of the chip idle (one frame per chain, deep layers of small micro-batches) spreads the 16
+            // Winograd positions of a tile over 16 / PN workgroups (k_conv_wino_ps): the same sums, bit for bit -- a scheduling
+            // choice, which is why it MAY depend on B.  PN = the coarsest split that still gives every CU a workgroup; launches
+            // that fill a quarter of the chip or more stay on k_conv_wino (measured at one frame: 128 workgroups of k_conv_wino
+            // beat 512 of the split form on the 256x256 layers, 64 lose to 256 on the 128x128 ones).
+            const long long wgs = (long long)a.n_spatial * n_ntiles;
+            int pn = 0;
+            if (h->wino_ps && h->d_partial != nullptr && h->d_tile_counter != nullptr && wgs * 4 <= h->n_cu && wgs <= 4096 &&
+                (size_t)wgs * (16 * 4 * 1024 * sizeof(float)) <= kPartialBytes) {
+                pn = (wgs * 4 >= h->n_cu) ? 4 : (wgs * 8 >= h->n_cu) ? 2 : 1;
+                if (h->wino_ps > 1) pn = (h->wino_ps == 2) ? 4 : (h->wino_ps == 3) ? 2 : 1;   // forced (tests, A/B)
+            }
+            if (pn) {
+                a.partial = h->d_partial;
+                a.tile_counter = h->d_tile_counter;
+                static const char* nm[2][3] = {{"k_conv_wino_ps<1,1>", "k_conv_wino_ps<1,2>", "k_conv_wino_ps<1,4>"},
+                                               {"k_conv_wino_ps<2,1>", "k_conv_wino_ps<2,2>", "k_conv_wino_ps<2,4>"}};
+                prof_begin(h, L.name, nm[L.NT - 1][pn == 1 ? 0 : pn == 2 ? 1 : 2], fl);
+                if (L.NT == 2) rc = (pn == 1) ? launch_conv_wino_ps<2, 1>(ctx, a, n_ntiles) : (pn == 2) ? launch_conv_wino_ps<2, 2>(ctx, a, n_ntiles)
+                                                                                                        : launch_conv_wino_ps<2, 4>(ctx, a, n_ntiles);
+                else rc = (pn == 1) ? launch_conv_wino_ps<1, 1>(ctx, a, n_ntiles) : (pn == 2) ? launch_conv_wino_ps<1, 2>(ctx, a, n_ntiles)
+                                                                                             : launch_conv_wino_ps<1, 4>(ctx, a, n_ntiles);
+                prof_end(h);
+                return rc;
+            }
             prof_begin(h, L.name, L.NT == 2 ? "k_conv_wino<2>" : "k_conv_wino<1>", fl);
             rc = (L.NT == 2) ? launch_conv_wino<2>(ctx, a, n_ntiles) : launch_conv_wino<1>(ctx, a, n_ntiles);
         } else if (impl == 0) {
@@ -1565,6 +1622,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "splitk_nt1" && (value == 0 || value == 1)) slot = &h->splitk_nt1;
     else if (n == "wino" && (value == 0 || value == 1)) slot = &h->wino;
     else if (n == "wino_first" && (value == 0 || value == 1)) slot = &h->wino_first;
+    else if (n == "wino_ps" && value >= 0 && value <= 4) slot = &h->wino_ps;
     else if (n == "splitk_fused" && (value == 0 || value == 1)) slot = &h->splitk_fused;
     else if (n == "splitk_slots" && value >= 1 && value <= 4) slot = &h->splitk_slots;
     else if (n == "splitk_min_steps" && value >= 1 && value <= 9) slot = &h->splitk_min_steps;

@@ -1309,6 +1309,300 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
     else conv_epilogue_b<NT, 0, TH, 0, false>(a, o, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
 }
 
+// 16-byte device-scope (sc1: written through / read past this XCD's L2) store and load for the exchange of raw accumulators
+// between workgroups that may sit on different XCDs -- the 128-bit form of what __hip_atomic_store / __hip_atomic_load at agent
+// scope compile to (global_store_dword ... sc1).  The store is followed by one wait state for the same reason as
+// og_buffer_store16 (hipcc cannot see the data registers of an inline-asm store being reused).
+__device__ __forceinline__ void og_store16_dev(float* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
+}
+// The matching load goes through the compiler's own buffer-load builtin with the sc1 cache-policy bit (aux 16 on gfx94x/95x):
+// hipcc then tracks the outstanding load itself (an inline-asm load returns "immediately" as far as the register allocator
+// is concerned, and anything it does with the destination registers before our s_waitcnt is undefined behaviour).
+__device__ __forceinline__ f32x4 og_load16_dev(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 16));
+}
+
+// POSITION-SPLIT form of k_conv_wino for launches that cannot fill the chip (one frame per kernel chain: the 16x16 map of the
+// bottleneck is ONE tile x 8 column tiles = 8 workgroups of k_conv_wino on 256 CUs, each with a serial loop of 32 channel
+// chunks x 128 MFMAs).  The 16 Winograd positions of a tile are 16 INDEPENDENT GEMMs over the input channels, so they can go
+// to different workgroups without touching any sum: workgroup (tile, column tile, position group pg) runs positions
+// pg PN .. pg PN + PN - 1 -- for each the same V entries (same adds in the same order), the same U entries and the same MFMA
+// sequence (chunk by chunk, k pairs in the same order) as k_conv_wino -- and writes its raw accumulators to a.partial; the
+// LAST workgroup of a tile to arrive (a.tile_counter) reads all 16 positions back, runs k_conv_wino's output transform and the
+// shared epilogue.  Every accumulator holds the bits k_conv_wino computes, so the result is BIT-IDENTICAL to it whatever
+// arrives first: 16 / PN times the workgroups, no change of arithmetic -- unlike split-K, which re-associates the channel sum.
+//   V for one position (i, cc) needs only rows (ra, rb) and columns (ca, cb) of the 4x4 patch: B^T d B is, per axis,
+//   {x0 - x2, x1 + x2, x2 - x1, x1 - x3}; a workgroup's PN <= 4 positions share the row i, so it reads 8 of the 16 patch pixels.
+//   LDS: raw halo ring LA x 24 KB | V 2 x PN x 4 KB | U (LA + 1) x max(PN x UP, 4 KB).  Stage c + LA is fetched (LDS-DMA, counted
+//   vmcnt) while chunk c multiplies and chunk c + 1 is transformed; two barriers per chunk; one workgroup per CU.
+template <int NT, int PN>
+__global__ __launch_bounds__(256, 1) void k_conv_wino_ps(ConvArgs a) {
+    static_assert(PN == 1 || PN == 2 || PN == 4, "a workgroup's positions share one row of the 4x4 position grid");
+    constexpr int KC = 8 * NT;
+    constexpr int PB = KC * 4;
+    constexpr int SL = KC / 4;
+    constexpr int KS = KC / 8;
+    constexpr int TH = 32 / NT;
+    constexpr int RP = 18;
+    constexpr int RAW_PIX = (TH + 2) * RP;
+    constexpr int RAW_PIECES = RAW_PIX * SL;
+    constexpr int RAW_IT = (RAW_PIECES + 255) / 256;   // 6 | 5
+    constexpr int RAW_PAD = RAW_IT * 4096;             // every lane of every DMA instruction lands inside its buffer
+    constexpr int UP_BYTES = 32 * NT * PB;             // one position's weights: 4096 | 1024
+    constexpr int U_STAGE = (PN * UP_BYTES > 4096) ? PN * UP_BYTES : 4096;
+    constexpr int U_IT = U_STAGE / 4096;               // DMA instructions per wave and stage (all four waves issue all of them)
+    constexpr int NDMA = RAW_IT + U_IT;                // vector-memory instructions per wave and stage: what s_waitcnt counts
+    constexpr int NPG = 16 / PN;
+    // look-ahead: stage c + LA is requested while chunk c multiplies (measured with LA = 2: 0.76 us per chunk against ~0.35 us of
+    // work -- the loop waits for memory latency, one workgroup per CU has nobody else to hide it); PN = 4 has no LDS left for 3
+    constexpr int LA = (PN <= 2) ? 3 : 2;
+    constexpr int RS = LA, US = LA + 1;                // raw / U ring depths
+    constexpr int VB = RS * RAW_PAD;
+    constexpr int UB = VB + 2 * PN * 4096;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = (NT == 2) ? (wave & 1) : 0, wm = (NT == 2) ? (wave >> 1) : wave;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // grid.z = k_conv_wino's z (frame group x column tile x frame-in-group) x position group
+    const int bzf = (int)blockIdx.z;
+    const int pg = bzf % NPG, bz = bzf / NPG;
+    const int gz = a.zdiv << a.zgroup_shift;
+    const int q_ = (gz == 1) ? bz : (int)(((float)bz + 0.5f) * a.zrcp);
+    const int rz = bz - q_ * gz;
+    const int n_tile = rz >> a.zgroup_shift;
+    const int b = (q_ << a.zgroup_shift) + (rz & ((1 << a.zgroup_shift) - 1));
+    if (b >= a.frames) return;   // every position group of such a tile returns: nobody waits for it
+    // diagnostic timeline (og_unet_clock_probe only; nullptr on every product path): entry, loop start, loop end, exit
+    unsigned long long* const st = a.stamps ? a.stamps + 4ull * (((unsigned)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x < 1023u
+                                                                    ? ((unsigned)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x : 1023u) : nullptr;
+    if (st != nullptr && tid == 0) st[0] = __builtin_amdgcn_s_memtime();
+    const int ty0 = (int)blockIdx.y * TH, tx0 = (int)blockIdx.x * 16;
+    const int tile_id = ((b * a.tiles_y + (int)blockIdx.y) * a.tiles_x + (int)blockIdx.x) * a.zdiv + n_tile;
+    const int p0 = pg * PN;
+    const int pi = p0 >> 2, pc0 = p0 & 3;                 // row of the position grid, first column
+    const int ra = (pi == 0) ? 0 : (pi == 2) ? 2 : 1;     // B^T row pi = x[ra] (+ if pi == 1, else -) x[rb]
+    const int rb = (pi == 0) ? 2 : (pi == 1) ? 2 : (pi == 2) ? 1 : 3;
+    const bool rplus = pi == 1;
+
+    const og_i32x4 in_rsrc = og_make_rsrc(a.in + (long long)b * a.in_frame_stride + a.in_ch_off,
+                                          (unsigned)(a.in_frame_stride - a.in_ch_off) * 4u);
+    unsigned hoff[RAW_IT];   // as k_conv_wino: pixel (hy, hx) at index hy * RP + (hx & 1) * 9 + (hx >> 1)
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) {
+        const int id = it * 256 + tid;
+        const int p = id / SL, pc = id % SL;
+        const int hy = p / RP, r = p - hy * RP;
+        const int hx = (r >= 9) ? 2 * (r - 9) + 1 : 2 * r;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        const bool inb = id < RAW_PIECES && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        hoff[it] = inb ? (unsigned)((gy * a.W + gx) * a.in_pix_stride * 4 + pc * 16) : OG_OOB;
+    }
+    const unsigned lds0 = og_lds_addr(smem);
+    const int n_ck = a.n_chunks * (32 / KC);
+    const og_i32x4 w_rsrc = og_make_rsrc(a.wpk + (long long)n_tile * n_ck * (16 * UP_BYTES / 4), (unsigned)n_ck * (16u * UP_BYTES));
+    auto stage = [&](int ck) {   // raw halo of chunk ck -> raw[ck % RS], U of (chunk ck, positions p0 ..) -> U[ck % US]
+        const unsigned rbase_ = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((ck % RS) * RAW_PAD) + wave * 1024);
+#pragma unroll
+        for (int it = 0; it < RAW_IT; ++it) glds16b(hoff[it], in_rsrc, (unsigned)ck * PB, rbase_ + it * 4096);
+        const unsigned ubase_ = __builtin_amdgcn_readfirstlane(lds0 + UB + (unsigned)((ck % US) * U_STAGE) + wave * 1024);
+#pragma unroll
+        for (int i = 0; i < U_IT; ++i)   // (PN x UP < 4 KB: the tail of the 4 KB belongs to the next positions / chunk, or reads as zeros)
+            glds16b((unsigned)tid * 16u, w_rsrc, (unsigned)((ck * 16 + p0) * UP_BYTES + i * 4096), ubase_ + i * 4096);
+    };
+#pragma unroll
+    for (int i = 0; i < LA; ++i)
+        if (i < n_ck) stage(i);
+
+    // fragment / transform addressing: k_conv_wino's, with V and U counted from the start of a position's 4 KB / UP block
+    const int wxa = 2 * (li >> 3) + ((li >> 2) & 1);
+    const int nb = wn * 32 + li;
+    unsigned abase[KS], bbase[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+        if (NT == 2) {
+            abase[j] = lds0 + VB + ((4 * wm + (li & 3)) * 8 + wxa) * 64 + (((2 * j + lh) ^ (li & 3)) << 4);
+            bbase[j] = lds0 + UB + nb * 64 + (((2 * j + lh) ^ ((nb >> 2) & 3)) << 4);
+        } else {
+            abase[j] = lds0 + VB + (8 * (4 * wm + (wxa >> 1)) + (li & 3) + 4 * (wxa & 1)) * 32 + ((lh ^ ((wxa >> 1) & 1)) << 4);
+            bbase[j] = lds0 + UB + nb * 32 + ((lh ^ ((nb >> 3) & 1)) << 4);
+        }
+    }
+    const int qc = tid % SL;
+    const int wr = (NT == 2) ? (tid >> 5) : 4 * (tid >> 6) + ((tid >> 2) & 3);
+    const int wc = (NT == 2) ? ((tid >> 2) & 7) : ((tid >> 1) & 1) + 2 * ((tid >> 4) & 3);
+    const int wt = 8 * wr + wc;
+    const unsigned rbase = lds0 + (unsigned)((2 * wr * RP + wc) * PB + qc * 16);
+    const unsigned vwbase = (NT == 2) ? lds0 + VB + (unsigned)(wt * 64 + ((qc ^ (wr & 3)) << 4))
+                                      : lds0 + VB + (unsigned)((8 * (4 * (wr >> 2) + (wc >> 1)) + (wr & 3) + 4 * (wc & 1)) * 32 + ((qc ^ ((wc >> 1) & 1)) << 4));
+
+    int issued = ((n_ck < LA) ? n_ck : LA) - 1;   // newest stage requested so far
+    auto wait_landed = [&](int ck) {   // stage ck has landed; the `issued - ck` younger ones may still be in flight (vmcnt retires in order)
+        const int newer = issued - ck;
+        if (LA >= 3 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else og_wait_dma();
+    };
+    // transform of chunk ck, in two halves so that the LDS latency of its reads hides under the MFMAs of chunk ck - 1.
+    // B^T d B per axis is x[ia] +- x[ib] with (ia, ib, sign) = (0,2,-) (1,2,+) (2,1,-) (1,3,-): the sign rides as a +-1 multiplier in
+    // ONE fma -- fma(+-1, b, a) rounds a +- b once, exactly like the add / subtract k_conv_wino issues -- so a runtime position
+    // costs no select; PN = 1 reads just the 4 patch pixels (rows ra, rb x columns ca, cb) of its position, PN = 2 the 3 columns
+    // of its two positions, PN = 4 all four.  (Measured before: the transform was 8.7 of the 22.8 us of the deepest layer's loop.)
+    const float rsgn = rplus ? 1.0f : -1.0f;
+    constexpr int NCOL = (PN == 1) ? 2 : (PN == 2) ? 3 : 4;
+    int colj[NCOL];   // patch columns read, in register order
+    if (PN == 1) {
+        colj[0] = (pc0 == 0) ? 0 : (pc0 == 2) ? 2 : 1;                    // ca
+        colj[1] = (pc0 == 0) ? 2 : (pc0 == 1) ? 2 : (pc0 == 2) ? 1 : 3;    // cb
+    } else if (PN == 2) {   // positions (0,1): columns 0,1,2; positions (2,3): columns 1,2,3
+        colj[0] = pc0 ? 1 : 0;
+        colj[1] = pc0 ? 2 : 1;
+        colj[NCOL - 1] = pc0 ? 3 : 2;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) colj[j] = j;
+    }
+    f32x4 xa[NCOL], xb[NCOL];
+    auto tr_read = [&](int ck) {   // patch pixel (row, j) of the window: index (2 wr + row) * RP + (j & 1) * 9 + wc + (j >> 1)
+        const unsigned rb_ = rbase + (unsigned)((ck % RS) * RAW_PAD);
+#pragma unroll
+        for (int n = 0; n < NCOL; ++n) {
+            const int j = colj[n];
+            xa[n] = og_lds_read16(rb_ + (unsigned)((ra * RP + (j & 1) * 9 + (j >> 1)) * PB));
+            xb[n] = og_lds_read16(rb_ + (unsigned)((rb * RP + (j & 1) * 9 + (j >> 1)) * PB));
+        }
+    };
+    auto fma4 = [](float sgn, f32x4 b_, f32x4 a_) {
+        return f32x4{fmaf(sgn, b_.x, a_.x), fmaf(sgn, b_.y, a_.y), fmaf(sgn, b_.z, a_.z), fmaf(sgn, b_.w, a_.w)};
+    };
+    auto tr_write = [&](int ck) {   // -> V[ck & 1][0 .. PN)
+        f32x4 t[NCOL];
+#pragma unroll
+        for (int n = 0; n < NCOL; ++n) t[n] = fma4(rsgn, xb[n], xa[n]);
+#pragma unroll
+        for (int k = 0; k < PN; ++k) {
+            f32x4 v;
+            if (PN == 1) v = fma4((pc0 == 1) ? 1.0f : -1.0f, t[1], t[0]);
+            else if (PN == 2) {   // t = columns (0,1,2) -> c0 = t0 - t2, c1 = t1 + t2 | columns (1,2,3) -> c2 = t2 - t1 = t[1] - t[0], c3 = t1 - t3 = t[0] - t[2]
+                if (k == 0) v = pc0 ? fma4(-1.0f, t[0], t[1]) : fma4(-1.0f, t[2], t[0]);
+                else v = pc0 ? fma4(-1.0f, t[2], t[0]) : fma4(1.0f, t[2], t[1]);
+            } else v = (k == 0) ? t[0] - t[2] : (k == 1) ? t[1] + t[2] : (k == 2) ? t[2] - t[1] : t[1] - t[3];
+            *(OG_LDS_AS f32x4*)(unsigned long long)(vwbase + (unsigned)(((ck & 1) * PN + k) * 4096)) = v;
+        }
+    };
+
+    f32x16 acc[PN];
+#pragma unroll
+    for (int k = 0; k < PN; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    wait_landed(0);
+    __syncthreads();
+    tr_read(0);
+    tr_write(0);
+    if (n_ck > 1) wait_landed(1);
+    if (st != nullptr && tid == 0) st[1] = __builtin_amdgcn_s_memtime();
+
+    // ONE barrier per chunk: behind it V[c & 1] is complete, the raw halo of chunk c + 1 has landed for every wave, and the
+    // buffers of stage c + LA (raw[c % RS]: transformed an iteration ago; U[(c - 1) % US]: multiplied an iteration ago) are free
+    for (int c = 0; c < n_ck; ++c) {
+        __syncthreads();
+        if (c + LA < n_ck) {
+            stage(c + LA);
+            issued = c + LA;
+        }
+        if (c + 1 < n_ck) tr_read(c + 1);
+        const unsigned vo = (unsigned)((c & 1) * PN * 4096), uo = (unsigned)((c % US) * U_STAGE);
+        // fragments of step s + 1 are requested before the MFMAs of step s (measured without: 770 cycles per position and chunk
+        // for 512 cycles of MFMA -- the LDS latency of every fragment pair was exposed)
+        f32x4 fa[2], fb[2];
+        fa[0] = og_lds_read16(abase[0] + vo);
+        fb[0] = og_lds_read16(bbase[0] + uo);
+#pragma unroll
+        for (int s_ = 0; s_ < PN * KS; ++s_) {
+            const int k = s_ / KS;
+            if (s_ + 1 < PN * KS) {
+                const int kn = (s_ + 1) / KS, jn = (s_ + 1) % KS;
+                fa[(s_ + 1) & 1] = og_lds_read16(abase[jn] + vo + (unsigned)(kn * 4096));
+                fb[(s_ + 1) & 1] = og_lds_read16(bbase[jn] + uo + (unsigned)(kn * UP_BYTES));
+            }
+            const f32x4 av = fa[s_ & 1], bv = fb[s_ & 1];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[k], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c + 1 < n_ck) tr_write(c + 1);
+        if (c + 2 < n_ck) wait_landed(c + 2);
+    }
+
+    if (st != nullptr && tid == 0) st[2] = __builtin_amdgcn_s_memtime();
+    // ---- raw accumulators out (16 B per lane and store, device scope), arrival, and for the last arriver: k_conv_wino's tail ----
+    float* const part = a.partial + (long long)tile_id * (16 * 4 * 1024) + wave * 1024 + lane * 4;
+#pragma unroll
+    for (int k = 0; k < PN; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            og_store16_dev(part + (p0 + k) * 4096 + q * 256, f32x4{acc[k][4 * q], acc[k][4 * q + 1], acc[k][4 * q + 2], acc[k][4 * q + 3]});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part is written through
+    __syncthreads();
+    int* const flag = (int*)smem;
+    if (tid == 0) *flag = (atomicAdd(a.tile_counter + tile_id, 1) == NPG - 1) ? 1 : 0;
+    __syncthreads();
+    if (*(volatile int*)flag == 0) {
+        if (st != nullptr && tid == 0) st[3] = __builtin_amdgcn_s_memtime();
+        return;
+    }
+    __syncthreads();   // the flag word is part of wave 0's epilogue scratch
+
+    const int ecol = n_tile * 32 * NT + wn * 32 + li;
+    const float esc = a.scale[ecol], esh = a.shift[ecol];
+    const __amdgpu_buffer_rsrc_t part_rs = og_rsrc(a.partial + (long long)tile_id * (16 * 4 * 1024), 16u * 4u * 1024u * 4u);
+    const unsigned part_voff = (unsigned)((wave * 1024 + lane * 4) * 4);
+    f32x16 o[4];
+    {   // all 16 positions x 16 accumulator registers of this lane (its own part from memory too): 64 loads in flight together --
+        // ONE memory round trip for the tile (the wave has 512 registers to itself)
+        f32x4 mm[4][16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) mm[q][k] = og_load16_dev(part_rs, part_voff, (unsigned)((k * 4096 + q * 256) * 4));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4* const m = mm[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {   // Y = A^T M A exactly as k_conv_wino writes it (register r = 4q + e)
+                float tm[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    tm[0][j] = m[0 + j][e] + m[4 + j][e] + m[8 + j][e];
+                    tm[1][j] = m[4 + j][e] - m[8 + j][e] - m[12 + j][e];
+                }
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    o[e][4 * q + 2 * y + 0] = tm[y][0] + tm[y][1] + tm[y][2];
+                    o[e][4 * q + 2 * y + 1] = tm[y][1] - tm[y][2] - tm[y][3];
+                }
+            }
+        }
+    }
+    unsigned char* const scr = smem + wave * 5120;
+    if (a.act == 1) conv_epilogue_b<NT, 0, TH, 1, false>(a, o, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+    else conv_epilogue_b<NT, 0, TH, 0, false>(a, o, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+    if (tid == 0) a.tile_counter[tile_id] = 0;   // ready for the next launch on this stream
+    if (st != nullptr && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st[3] = __builtin_amdgcn_s_memtime() | (1ull << 63);   // top bit: this workgroup reduced its tile
+    }
+}
+
 // Split-precision twin of k_conv_mfma_o (MODE 0: 3x3 conv, MODE 1: 2x2 stride-2 transposed conv): same tiles, halo /
 // weight staging, LDS images, swizzles and fragment addressing; the operands are f16 hi/lo pairs in the H layout and each
 // (chunk, tap) costs 6 x v_mfma_f32_32x32x16_f16 per 32-row sub-tile instead of 16 x v_mfma_f32_32x32x2_f32.  No split-K.

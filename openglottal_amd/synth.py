@@ -136,6 +136,23 @@ def glottis_frames(
     return np.stack(frames), np.stack(gts)
 
 
+def degraded_glottis_frames(n_patients: int = 2, n_frames: int = 12, seed: int = 4242) -> tuple[np.ndarray, np.ndarray]:
+    """Glottis frames a trained net is UNSURE about: contrast reduced to 25-75 % and Gaussian noise of sigma 12-32 added.
+    The full-width trained fixture (tests/golden/unet_trained_full.npz) is evaluated on them as well: Dice anywhere between 0
+    and 1 and logit margins down to 1e-3, i.e. the boundary-pixel situation of a real recording rather than the clean
+    synthetic frames' margins of 0.1 and more.  Returns (frames u8 [N,256,256], gt u8)."""
+    fr, gt = glottis_frames(n_patients, n_frames, seed=seed)
+    rs = np.random.RandomState(seed + 1)
+    out = np.empty_like(fr)
+    for i, f in enumerate(fr):
+        x = f.astype(np.float32)
+        m = x.mean()
+        c = 0.25 + 0.5 * rs.rand()
+        x = (x - m) * c + m + rs.normal(0.0, 12.0 + 20.0 * rs.rand(), x.shape)
+        out[i] = np.clip(np.rint(x), 0, 255).astype(np.uint8)
+    return out, gt
+
+
 def full128_frames() -> tuple[np.ndarray, np.ndarray]:
     """The 128 frames of the bench-configuration fixture (tests/golden/unet_full128.npz): the 80-frame structured
     GIRAFE stand-in (4 "patients" x 20 frames, ``glottis_frames(4, 20, seed=99)``) followed by frames 0..47 of the

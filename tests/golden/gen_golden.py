@@ -208,10 +208,10 @@ def gen_self_noise(UNet, meta) -> None:
                                        "flips_channels_last": int(len(out["channels_last_flip_frame"]))}
 
 
-def gen_trained_full(UNet, unet_segment_frame, dice, iou, dice_loss, meta, steps: int = 300) -> None:
+def gen_trained_full(UNet, unet_segment_frame, dice, iou, dice_loss, meta, steps: int = 300, train: bool = True) -> None:
     """(9) FULL-WIDTH trained net: the reference's `UNet(1,1,(32,64,128,256))` trained here with the reference's recipe
     (AdamW 1e-3, 0.5 BCE + 0.5 Dice, `scripts/train_unet.py:141,155-157`, `utils.py:209-213`) on the synthetic glottis
-    frames, every tensor then rounded to float16-representable values (weights are data; halves the file), and the ROUNDED
+    frames, every convolution kernel then rounded to float16-representable values (weights are data; halves the file), and the ROUNDED
     net evaluated by the reference's `unet_segment_frame` on the 80-frame GIRAFE stand-in: bit-packed masks, integer areas,
     Dice/IoU vs GT, sampled logits, the smallest |logit| per frame.  A trained net has the margins a real checkpoint has,
     so the GPU test compares masks and areas EXACTLY (no flip rule)."""
@@ -222,8 +222,12 @@ def gen_trained_full(UNet, unet_segment_frame, dice, iou, dice_loss, meta, steps
     from openglottal_amd import synth
 
     feats = (32, 64, 128, 256)
+    out_path = os.path.join(HERE, "unet_trained_full.npz")
     torch.manual_seed(2)
     tm = UNet(1, 1, feats)
+    if not train:   # re-evaluate the committed weights (another frame set, another statistic) without the 15-minute training
+        old = np.load(out_path)
+        steps = int(meta.get("trained_full", {}).get("steps", steps))
     opt = torch.optim.AdamW(tm.parameters(), lr=1e-3)
     tr_x, tr_y = synth.glottis_frames(12, 20, seed=1001)
     tx = torch.from_numpy(tr_x.astype("float32") / 255.0).unsqueeze(1)
@@ -231,7 +235,7 @@ def gen_trained_full(UNet, unet_segment_frame, dice, iou, dice_loss, meta, steps
     tm.train()
     g = torch.Generator().manual_seed(4)
     t0 = time.time()
-    for step in range(steps):
+    for step in range(steps if train else 0):
         idx = torch.randint(0, tx.shape[0], (8,), generator=g)
         lo = tm(tx[idx])
         loss = 0.5 * torch.nn.functional.binary_cross_entropy_with_logits(lo, ty[idx]) + 0.5 * dice_loss(lo, ty[idx])
@@ -242,32 +246,35 @@ def gen_trained_full(UNet, unet_segment_frame, dice, iou, dice_loss, meta, steps
             print(f"  full-width train step {step} loss {float(loss):.4f} ({time.time() - t0:.0f} s)", flush=True)
     tsd = {}
     for k, v in tm.state_dict().items():
-        a = v.detach().numpy()
+        a = old["W:" + k] if not train else v.detach().numpy()
         if k.endswith("num_batches_tracked"):
             tsd[k] = a.astype(np.int64)
-            continue
-        h = a.astype(np.float16)
-        if k.endswith("running_var"):
-            h = np.maximum(h, np.float16(1e-4))   # keep the variance a normal positive half
-        tsd[k] = h
+        elif a.ndim >= 2:                      # convolution kernels (99.9 % of the bytes): float16-representable values
+            tsd[k] = a.astype(np.float16)
+            assert np.isfinite(tsd[k]).all(), k
+        else:                                  # BN affine / running statistics, biases: 6 k numbers, kept as float32 (a running
+            tsd[k] = a.astype(np.float32)      # variance of 1e5 does not fit a half)
     tm.load_state_dict({k: torch.from_numpy(v.astype(np.float32) if v.dtype == np.float16 else v) for k, v in tsd.items()})
     tm.eval()
     dev = torch.device("cpu")
-    ev_x, ev_y = synth.glottis_frames(4, 20, seed=99)   # the 80-frame GIRAFE stand-in
+    ev_x, ev_y = synth.glottis_frames(4, 20, seed=99)   # the 80-frame GIRAFE stand-in ...
+    hx, hy = synth.degraded_glottis_frames()              # ... + 24 degraded frames the net is unsure about (margins ~1e-3)
+    ev_x, ev_y = np.concatenate([ev_x, hx]), np.concatenate([ev_y, hy])
+    NF = len(ev_x)
     ev_masks = np.stack([unet_segment_frame(f, tm, dev) for f in ev_x])
-    ev_logits = np.empty((80, 256, 256), np.float32)
+    ev_logits = np.empty((NF, 256, 256), np.float32)
     with torch.no_grad():
-        for i in range(80):
+        for i in range(NF):
             ev_logits[i] = tm(torch.from_numpy(ev_x[i:i + 1].astype("float32") / 255.0).unsqueeze(1)).numpy()[0, 0]
     assert np.array_equal(ev_masks > 0, ev_logits > 0)
     ev_areas = np.array([int(np.sum(m > 0)) for m in ev_masks], dtype=np.int64)
     ev_dice = np.array([dice(m, g_) for m, g_ in zip(ev_masks, ev_y)])
     ev_iou = np.array([iou(m, g_) for m, g_ in zip(ev_masks, ev_y)])
     samp = np.random.RandomState(9).choice(256 * 256, size=1024, replace=False).astype(np.int32)
-    flat = ev_logits.reshape(80, -1)
+    flat = ev_logits.reshape(NF, -1)
     near = np.argwhere(np.abs(flat) < 1e-3)
     np.savez_compressed(
-        os.path.join(HERE, "unet_trained_full.npz"),
+        out_path,
         features=np.array(feats),
         **{"W:" + k: v for k, v in tsd.items()},
         masks_packed=np.stack([packbits(m) for m in ev_masks]),
@@ -277,9 +284,12 @@ def gen_trained_full(UNet, unet_segment_frame, dice, iou, dice_loss, meta, steps
         near_zero_frame=near[:, 0].astype(np.int32), near_zero_pixel=near[:, 1].astype(np.int32),
         near_zero_logit=flat[near[:, 0], near[:, 1]].astype(np.float32),
     )
-    meta["trained_full"] = {"steps": steps, "mean_dice": float(ev_dice.mean()), "mean_iou": float(ev_iou.mean()),
-                            "abs_logit_min": float(np.abs(flat).min()), "n_abs_logit_lt_1e3": int(len(near)),
-                            "areas_first8": ev_areas[:8].tolist()}
+    meta["trained_full"] = {"steps": steps, "frames": "80 clean (glottis_frames(4,20,seed=99)) + 24 degraded (degraded_glottis_frames())",
+                            "mean_dice_clean80": float(ev_dice[:80].mean()), "mean_iou_clean80": float(ev_iou[:80].mean()),
+                            "mean_dice_degraded24": float(ev_dice[80:].mean()),
+                            "abs_logit_min_clean80": float(np.abs(flat[:80]).min()), "abs_logit_min_degraded24": float(np.abs(flat[80:]).min()),
+                            "n_abs_logit_lt_1e3": int(len(near)), "n_abs_logit_lt_1e2": int((np.abs(flat) < 1e-2).sum()),
+                            "areas_first8": ev_areas[:8].tolist(), "areas_degraded": ev_areas[80:].tolist()}
     print("trained full: mean dice", ev_dice.mean(), "areas", ev_areas[:10], "min|logit|", np.abs(flat).min(), "n<1e-3:", len(near))
 
 
@@ -308,9 +318,10 @@ def main() -> None:
             gen_full128(UNet, unet_segment_frame, dice, iou, meta)
         elif which == "self_noise":
             gen_self_noise(UNet, meta)
-        elif which == "trained_full":
+        elif which in ("trained_full", "trained_full_eval"):
             torch.set_num_threads(int(os.environ.get("OG_GEN_THREADS", "8")))
-            gen_trained_full(UNet, unet_segment_frame, dice, iou, dice_loss, meta, steps=int(os.environ.get("OG_GEN_STEPS", "300")))
+            gen_trained_full(UNet, unet_segment_frame, dice, iou, dice_loss, meta, steps=int(os.environ.get("OG_GEN_STEPS", "400")),
+                             train=(which == "trained_full"))
         else:
             raise SystemExit(f"unknown section {which}")
         with open(os.path.join(HERE, "meta.json"), "w") as f:
@@ -524,7 +535,7 @@ def main() -> None:
     # ── (7) full width, 128 frames: C1 stand-in + the bench configuration's pin ──
     gen_full128(UNet, unet_segment_frame, dice, iou, meta)
     gen_self_noise(UNet, meta)
-    gen_trained_full(UNet, unet_segment_frame, dice, iou, dice_loss, meta)
+    gen_trained_full(UNet, unet_segment_frame, dice, iou, dice_loss, meta, steps=400)
 
     with open(os.path.join(HERE, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1)

@@ -7,9 +7,14 @@ two lanes, hipGraph replay, fused head, every 3x3 layer behind the first in Wino
 against tests/golden/unet_full128.npz, which tests/golden/gen_golden.py captured from the reference's own
 `unet_segment_frame` (openglottal/utils.py:218-241) and metric definitions (scripts/eval_girafe.py:113-124).
 
-Flip rule (as test_gpu_parity.py): a mask pixel may differ from the reference only where the REFERENCE's logit is
-within 5e-5 of zero (fp32 re-association noise; the reference is not bit-reproducible across oneDNN thread counts);
-the area may differ by at most the number of such flips.
+Flip rule: a mask pixel may differ from the reference only where the REFERENCE's logit is within BAND of zero; the area
+may differ by at most the number of such flips.  BAND is not a number chosen here: it is the largest difference the
+reference shows AGAINST ITSELF on these very frames (tests/golden/unet_full128_self_noise.npz, captured by gen_golden.py:
+`UNet.forward` with 1 oneDNN thread instead of 8 -> 2.4e-6, 0 sign flips; with the channels_last memory format -> 3.5e-5,
+13 sign flips of 8 388 608).  An f32 implementation with another summation order can be held to that band, not to less.
+
+The TRAINED full-width net (unet_trained_full.npz: the reference's model + loss trained here, 80 clean + 24 degraded frames,
+margins down to 8e-4) needs no band at all: masks and areas are compared exactly.
 """
 import os
 
@@ -21,7 +26,10 @@ from openglottal_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-TOL = 5e-5
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BAND = float(np.load(os.path.join(GOLD, "unet_full128_self_noise.npz"))["band"])    # the reference's own run-to-run difference
+assert 1e-6 < BAND < 1e-4, BAND
+TOL = BAND
 DOMINANT = "k_conv_wino<2>"
 DOMINANT_DIRECT = "k_conv_mfma_o<2,0,16>"
 
@@ -108,7 +116,7 @@ def test_bench_configuration_against_reference_fixture(setup):
         assert kernels[0] == "k_conv_mfma_o<1,0,8,FIRST>", kernels
     finally:
         m.set_option("wino", 1)
-    assert np.abs(lg_w - logits.cpu().numpy()).max() <= TOL
+    assert np.abs(lg_w - logits.cpu().numpy()).max() <= 2 * BAND   # two forms, each within BAND of the reference
 
 
 def test_bench_configuration_host_entry_and_latency_mode(setup):
@@ -130,3 +138,51 @@ def test_bench_configuration_host_entry_and_latency_mode(setup):
             assert abs(nz.get((i, int(p)), 1.0)) <= TOL
         assert abs(int(ar1[i]) - int(g["areas"][i])) <= len(flips)
         assert np.abs(lg1[i].ravel()[g["sample_idx"]] - g["logits_samples"][i]).max() <= TOL
+
+
+def test_trained_full_width_net_exact_in_bench_configuration(golden_dir):
+    """"area integers bit-exact" at FULL width with trained margins.  104 frames (the 80-frame GIRAFE
+    stand-in + 24 degraded frames on which the net is unsure: Dice 0..1, |logit| down to 8e-4) through bench.py's
+    configuration (64 frames per chain, two lanes, graphs, Winograd form asserted): every mask pixel and every area integer
+    equal to the reference's, no flip rule; Dice vs GT equal to the reference's Dice to 1e-12."""
+    import torch
+
+    g = np.load(os.path.join(golden_dir, "unet_trained_full.npz"))
+    feats = tuple(int(f) for f in g["features"])
+    sd = {k[2:]: (g[k].astype(np.float32) if g[k].dtype == np.float16 else g[k]) for k in g.files if k.startswith("W:")}
+    m = og.UNet(1, 1, feats)
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    m.set_chunk(64)
+    m.set_graphs(True)
+    m.set_option("dual", 1)
+    clean, gt_c = synth.glottis_frames(4, 20, seed=99)
+    hard, gt_h = synth.degraded_glottis_frames()
+    frames, gt = np.concatenate([clean, hard]), np.concatenate([gt_c, gt_h])
+    n = len(frames)
+    assert n == len(g["areas"]) == 104
+    dev = torch.device("cuda", 0)
+    fdev = torch.from_numpy(frames).to(dev)
+    area = torch.zeros(n, dtype=torch.int32, device=dev)
+    mask = torch.zeros((n, 256, 256), dtype=torch.uint8, device=dev)
+    logits = torch.zeros((n, 256, 256), dtype=torch.float32, device=dev)
+    for rep in range(2):
+        m.segment_dev(fdev, n, 256, 256, area, mask_dev=mask, logits_dev=logits)
+        m.sync()
+        mk, ar, lg = mask.cpu().numpy(), area.cpu().numpy(), logits.cpu().numpy()
+        ref = np.unpackbits(g["masks_packed"], axis=1)[:, :65536].reshape(n, 256, 256)
+        assert np.array_equal(mk > 0, ref > 0), int(((mk > 0) != (ref > 0)).sum())          # 104 x 65 536 pixels, exactly
+        assert np.array_equal(ar.astype(np.int64), g["areas"])                                # the area waveform's integers, exactly
+        err = np.abs(lg.reshape(n, -1)[:, g["sample_idx"]] - g["logits_samples"]).max()
+        assert err <= BAND * max(1.0, float(np.abs(g["logits_samples"]).max())), err
+        d = np.array([og.dice(mk[i], gt[i]) for i in range(n)])
+        assert np.abs(d - g["dice_vs_gt"]).max() <= 1e-12
+    kernels = [p["kernel"] for p in m.profile(fdev, 64, 256, 256, reps=1)]
+    assert kernels.count("k_conv_wino<2>") == 14 and kernels.count("k_conv_wino<1>") == 3, kernels
+    # the reference's per-frame call pattern and the streamed frame loop give the same integers (one-frame launches run the
+    # position-split kernels: same sums)
+    from openglottal_amd.features import area_waveform
+    assert np.array_equal(area_waveform(frames, None, m).astype(np.int64), g["areas"])
+    for i in (3, 85, 97):
+        assert np.array_equal(og.unet_segment_frame(frames[i], m, "cuda:0") > 0, ref[i] > 0), i
+    print(f"trained full-width: 104 frames exact; max sampled |dlogit| {err:.2e}; smallest |reference logit| {float(g['abs_logit_min'].min()):.2e}")

@@ -128,6 +128,8 @@ def test_same_kernels_at_every_micro_batch_size(base):
 
     def form(kernel):
         assert "splitK" not in kernel, kernel
+        if kernel.startswith("k_conv_wino_ps<"):     # position-split launch of the same form (same sums, more workgroups)
+            return "k_conv_wino<" + kernel.split("<")[1].split(",")[0] + ">"
         return kernel if kernel.startswith(("k_conv_wino", "k_conv_first")) else "direct:" + kernel.split("<")[1].split(",")[1]   # MODE
 
     k64 = [(p["layer"], form(p["kernel"])) for p in m.profile(d, 64, 256, 256, reps=1)]
@@ -137,6 +139,35 @@ def test_same_kernels_at_every_micro_batch_size(base):
     names = [k for _, k in k64]
     assert names.count("k_conv_wino<2>") == 14 and names.count("k_conv_wino<1>") == 3, names
     assert not any("splitK" in k for k in names), names
+
+
+def test_position_split_launches_are_bit_identical(base):
+    """k_conv_wino_ps (under-filled launches: a tile's 16 Winograd positions on 16 / PN workgroups, last arriver reduces)
+    against k_conv_wino: every PN, one to three frames per chain, repeated (arrival order varies), logits bit for bit."""
+    import torch
+
+    m, fr, masks, areas, logits = base
+    n = 12
+    try:
+        for ps, tag in [(0, None), (1, "auto"), (2, ",4>"), (3, ",2>"), (4, ",1>")]:
+            m.set_option("wino_ps", ps)
+            for chunk in (1, 3):
+                m.set_chunk(chunk)
+                for rep in range(2):
+                    mk, ar, lg = m.segment(fr[:n], want_logits=True)
+                    assert np.array_equal(lg, logits[:n]), (ps, chunk, rep, float(np.abs(lg - logits[:n]).max()))
+                    assert np.array_equal(ar, areas[:n]) and np.array_equal(mk, masks[:n]), (ps, chunk, rep)
+            names = [p["kernel"] for p in m.profile(torch.from_numpy(fr[:1]).to("cuda:0"), 1, 256, 256, reps=1)]
+            n_ps = sum(k.startswith("k_conv_wino_ps") for k in names)
+            if ps == 0:
+                assert n_ps == 0, names
+            elif tag == "auto":
+                assert n_ps >= 10, names          # every 3x3 layer behind the first two levels is under-filled at one frame
+            else:
+                assert n_ps >= 10 and all(k.endswith(tag) for k in names if k.startswith("k_conv_wino_ps")), names
+    finally:
+        m.set_option("wino_ps", 1)
+        m.set_chunk(64)
 
 
 def _rank(rank, world, port, q):

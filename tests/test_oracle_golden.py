@@ -114,3 +114,33 @@ def test_full_width_128_frame_fixture_subset(golden_dir):
         if i < 80:
             from openglottal_amd.utils import dice
             assert abs(dice(masks[j], gt[i]) - float(g["dice_vs_gt"][i])) <= 1e-3
+
+
+def test_trained_full_width_fixture_subset(golden_dir):
+    """The oracle against the TRAINED full-width fixture (reference model + loss trained in the build container, evaluated by
+    the reference's `unet_segment_frame`): 6 clean + 6 degraded frames here, all 104 on the GPU.  Masks exact (margins >= 8e-4)."""
+    g = np.load(os.path.join(golden_dir, "unet_trained_full.npz"))
+    sd = {k[2:]: (g[k].astype(np.float32) if g[k].dtype == np.float16 else g[k]) for k in g.files if k.startswith("W:")}
+    clean, _ = synth.glottis_frames(4, 20, seed=99)
+    hard, _ = synth.degraded_glottis_frames()
+    frames = np.concatenate([clean, hard])
+    sel = [0, 5, 33, 47, 62, 79, 80, 84, 89, 93, 99, 103]
+    masks, logits = O.segment_frames(sd, frames[sel], backend="torch")
+    for j, i in enumerate(sel):
+        assert np.abs(logits[j].ravel()[g["sample_idx"]] - g["logits_samples"][i]).max() <= LOGIT_TOL * max(1.0, float(np.abs(g["logits_samples"][i]).max())), i
+        assert np.array_equal(masks[j] > 0, unpack(g["masks_packed"][i]) > 0), i
+        assert int((masks[j] > 0).sum()) == int(g["areas"][i])
+
+
+def test_reference_self_noise_band_is_what_the_tests_use(golden_dir):
+    """The flip band of the full-width GPU tests is the reference's own run-to-run difference, stored next to the fixture."""
+    import json
+    z = np.load(os.path.join(golden_dir, "unet_full128_self_noise.npz"))
+    band = float(z["band"])
+    assert band == max(float(z["threads1_max_abs_dlogit"].max()), float(z["channels_last_max_abs_dlogit"].max()))
+    assert 1e-6 < band < 1e-4
+    # every sign flip between two runs of the reference sits inside that band of the fixture's own logit
+    for v in ("threads1", "channels_last"):
+        assert np.all(np.abs(z[f"{v}_flip_base_logit"]) <= band)
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))
+    assert abs(meta["unet_full128_self_noise"]["band_max_abs_dlogit"] - band) < 1e-12
