@@ -156,21 +156,27 @@ int og_unet_reserve(og_unet* h, int frames_per_launch, int H, int W);
 /* 1 = replay captured hipGraphs for repeated shapes (default), 0 = eager launches. */
 int og_unet_set_graphs(og_unet* h, int enable);
 
-/* Kernel-selection knobs for A/B measurements (results are bit-identical across them):
+/* Kernel-selection knobs for A/B measurements (results are bit-identical across them, except "precision", "wino" and "splitk"):
  * "conv_impl" 0|1, "tps_nt1" 1|3|9, "tps_nt2" 1|3, "wg_per_cu" 1|2, "prio_mode" 0|1|2|3, "tile_h" 0|8|16,
  * "splitk_fused" 0|1 (the last-arriving K part of a tile reduces all parts in split order and runs the epilogue; 0: separate reduce launch),
  * "splitk_occ" 0|1 (K parts of a split launch on the occupancy kernel; 0: persistent kernel), "splitk_slots" 1..4 and "splitk_div" 1..8
  * (its target workgroups per CU / split when the launch fills less than 1/div of them),
  * "occ_min_pct" 0..400 (occupancy kernel when a launch has at least that many workgroups per 100 CUs), "convt_occ" 0|1, "fuse_first" 0|1 (first layer computed inside downs.0's second conv), "fuse_head" 0|1 (head +
  * threshold + area inside the last conv's epilogue), "keep_taps" 0|1, "precision" 0|1 (NOT bit-identical: 0 = exact f32, the default and the parity reference; 1 = opt-in split precision -- activations and weights as f16 hi/lo pairs, three v_mfma_f32_32x32x16_f16 per f32 product, f32 accumulation; passes the reference fixtures at the f32 tolerance, 2.5x faster; an activation beyond the f16 range makes the call fail with OG_ERANGE), "h_square" 0|1 (its wave tiling), "stream" 0|1 (og_unet_segment_u8 through the streaming engine, default 1; 0 = whole batch staged at once), "dual" 0|1 (micro-batches of one call alternate over extra lanes = streams/arenas, so that launch tails overlap) with "lanes" 0..3 (0 = 3 lanes up to 16 frames per launch, else 2), and
- * "splitk" 0|1 (1 = launches that would fill < 1/4 of the chip split K across workgroups; sums
- * are taken in a fixed order, so results are deterministic but differ in the last bits from the
- * unsplit order), "splitk_nt1" 0|1 (split launches of 64-column layers on 32-column tiles), "splitk_min_steps" 1..9.
- * "wino" 0|1 [1] (NOT bit-identical: 1 = the 3x3 convs of every kernel chain whose micro-batch fills the chip -- 32 frames at
- * 256x256 -- run in Winograd F(2x2,3x3) form, all f32: 16 MFMA multiplies per 2x2 output window and channel pair instead of 36,
- * transforms in f32 adds; same reference fixtures, same 5e-5 tolerance, measured closer to the reference than the direct form;
- * 0 = the direct kernels everywhere; smaller micro-batches always take the direct kernels), "wino_first" 0|1 (on such chains
- * the first layer runs unfused so that the second conv takes the Winograd kernel). */
+ * "wino_ps" 0..4 [1] (Winograd launches that fill less than a quarter of the CUs spread a tile's 16 positions over 16 / PN workgroups,
+ * k_conv_wino_ps: the same sums, bit for bit; 0 off, 1 auto, 2 / 3 / 4 force PN = 4 / 2 / 1).
+ *
+ * The two options that DO change the arithmetic:
+ * "wino" 0|1 [1]: the form of the HANDLE.  1 = every 3x3 conv whose map tiles (H, W multiples of 16; 32 rows for 32-column layers)
+ * runs in Winograd F(2x2,3x3) form, all f32 (16 MFMA multiplies per 2x2 output window and channel pair instead of 36, transforms in
+ * f32 adds) AT EVERY MICRO-BATCH SIZE, one frame per call included; 0 = the direct kernels everywhere.  Which layers take which form
+ * depends on the options and (H, W) only, never on B, the lane, the shard or the entry point: a frame's mask is a function of the frame
+ * alone, as in the reference's per-frame loop (features.py:234-238).  Both forms pass the same reference fixtures inside the
+ * reference's own run-to-run noise band.  "wino_first" 0|1 (first layer unfused so that the second conv takes the Winograd kernel).
+ * "splitk" 0|1 [0]: OPT-IN, non-canonical.  1 = launches that would fill < 1/div of the chip split K across workgroups ("wino" 0 layers
+ * and transposed convs); sums are taken in a fixed order, so results are deterministic, but they differ in the last bits from the
+ * unsplit order -- a frame's logits then depend on how many frames share its launch.  "splitk_nt1" 0|1 (split launches of 64-column
+ * layers on 32-column tiles), "splitk_min_steps" 1..9. */
 int og_unet_set_option(og_unet* h, const char* name, int value);
 
 /* HIP-event timing on the handle's stream (bench.py's roofline leg). */

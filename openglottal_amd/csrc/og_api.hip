@@ -115,7 +115,6 @@ struct og_unet {
                          // Which layers take it is a function of the handle's options and of (H, W) alone -- never of the micro-batch
                          // size, the lane, the shard or the entry point -- so a frame's mask is a function of the frame only
                          // (features.py:234-238 has no cross-frame state either).  0: the direct kernels for every layer.
-    int wino2 = 1;       // 32-column Winograd layers of chip-filling launches on k_conv_wino2 (two workgroups per CU; bit-identical)
     int wino_ps = 1;     // under-filled Winograd launches spread a tile's 16 positions over several workgroups (k_conv_wino_ps: bit-identical);
                          // 0 off, 1 auto, 2 / 3 / 4 force PN = 4 / 2 / 1 on every launch that qualifies
     int wino_first = 1;  // Winograd chains: first layer unfused so that the second conv takes k_conv_wino<1>
@@ -569,32 +568,6 @@ int launch_conv_wino(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {  
     return OG_OK;
 }
 
-// k_conv_wino2<1>: 16x16-pixel tiles, two workgroups per CU (76 KB of LDS each)
-constexpr int wino2_lds() { return 3 * 4096 + 16 * 64 * 32 + 2 * 16 * 1024; }
-
-int launch_conv_wino2(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
-    ConvArgs a = a_in;
-    a.stamps = nullptr;
-    a.ksplit = 1;
-    a.tile_counter = nullptr;
-    const int frames = a.n_spatial / (a.tiles_x * a.tiles_y);
-    a.zdiv = n_ntiles;
-    a.frames = frames;
-    a.zgroup_shift = 0;
-    if (c.xcd_group && a.zdiv > 1) {
-        int txy = a.tiles_x * a.tiles_y, g = 8;
-        while (g > 1 && txy % 2 == 0) { txy /= 2; g /= 2; }
-        while (g > frames) g /= 2;
-        while ((1 << a.zgroup_shift) < g) ++a.zgroup_shift;
-    }
-    const int G = 1 << a.zgroup_shift, groups = (frames + G - 1) / G;
-    a.zrcp = 1.0f / (float)(a.zdiv * G);
-    if ((long long)groups * G * a.zdiv > 65535) return fail(OG_EINVAL, "micro-batch too large for one launch (grid.z): lower the chunk size");
-    hipLaunchKernelGGL(k_conv_wino2<1>, dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), wino2_lds(), c.stream, a);
-    HIPCHK(hipGetLastError());
-    return OG_OK;
-}
-
 template <int NT, int PN>
 constexpr int wino_ps_lds() {
     constexpr int KC = 8 * NT, raw_it = ((32 / NT + 2) * 18 * (KC / 4) + 255) / 256, up = 32 * NT * KC * 4, la = (PN <= 2) ? 3 : 2;
@@ -695,7 +668,6 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 16>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino<2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds<2>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds<1>()));
-    HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wino2_lds()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_ps<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (wino_ps_lds<2, 1>())));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_ps<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (wino_ps_lds<2, 2>())));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_ps<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (wino_ps_lds<2, 4>())));
@@ -722,13 +694,6 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     if ((rc = set_conv_p_attr<2, 2, 8, 1>())) return rc;
     if ((rc = set_conv_p_attr<1, 2, 8, 1>())) return rc;
     return OG_OK;
-}
-
-// k_conv_wino2 instead of k_conv_wino<1>?  A scheduling choice between two kernels that compute the same bits: taken when the
-// launch has at least four 16x16 tiles per CU (two resident workgroups per CU, two rounds).
-bool use_wino2(const og_unet* h, const ConvLayer& L, int B, int H, int W) {
-    if (!h->wino2 || L.NT != 1 || H % 16 || W % 16) return false;
-    return (long long)B * (H / 16) * (W / 16) * (L.Cout_p / 32) >= 4LL * h->n_cu;
 }
 
 // in: activation view + channel offset/count; out likewise; pool optional
@@ -902,14 +867,6 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
             // that fill a quarter of the chip or more stay on k_conv_wino (measured at one frame: 128 workgroups of k_conv_wino
             // beat 512 of the split form on the 256x256 layers, 64 lose to 256 on the 128x128 ones).
             const long long wgs = (long long)a.n_spatial * n_ntiles;
-            if (use_wino2(h, L, B, in.H, in.W)) {   // 32-column layer, several tiles per CU: 16x16 tiles, two workgroups per CU (same sums)
-                a.tiles_y = in.H / 16;
-                a.n_spatial = B * a.tiles_x * a.tiles_y;
-                prof_begin(h, L.name, "k_conv_wino2<1>", fl);
-                rc = launch_conv_wino2(ctx, a, n_ntiles);
-                prof_end(h);
-                return rc;
-            }
             int pn = 0;
             if (h->wino_ps && h->d_partial != nullptr && h->d_tile_counter != nullptr && wgs * 4 <= h->n_cu && wgs <= 4096 &&
                 (size_t)wgs * (16 * 4 * 1024 * sizeof(float)) <= kPartialBytes) {
@@ -1129,8 +1086,7 @@ int enqueue_last_with_head(og_unet* h, int B, float thr, const int32_t* boxes, u
     const Act& u = h->UA[0];
     // count slots per frame: the fused launch runs on 8x16 tiles (direct kernel) or on 32x16 tiles (k_conv_wino<1>)
     const bool wino_last = h->wino_chain && h->dec_b[L - 1].d_ww != nullptr && u.H % 32 == 0 && u.W % 16 == 0;
-    const bool w2 = wino_last && use_wino2(h, h->dec_b[L - 1], B, u.H, u.W);   // 16x16 tiles (two of its four per-wave slots stay 0)
-    const int tiles = wino_last ? (u.W / 16) * (u.H / (w2 ? 16 : 32)) : ((u.W + 15) / 16) * ((u.H + 7) / 8);
+    const int tiles = wino_last ? (u.W / 16) * (u.H / 32) : ((u.W + 15) / 16) * ((u.H + 7) / 8);
     const size_t need = (size_t)B * tiles * 4;
     if (area && need > h->counts_cap) {
         if (h->d_counts) {
@@ -1667,7 +1623,6 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "wino" && (value == 0 || value == 1)) slot = &h->wino;
     else if (n == "wino_first" && (value == 0 || value == 1)) slot = &h->wino_first;
     else if (n == "wino_ps" && value >= 0 && value <= 4) slot = &h->wino_ps;
-    else if (n == "wino2" && (value == 0 || value == 1)) slot = &h->wino2;
     else if (n == "splitk_fused" && (value == 0 || value == 1)) slot = &h->splitk_fused;
     else if (n == "splitk_slots" && value >= 1 && value <= 4) slot = &h->splitk_slots;
     else if (n == "splitk_min_steps" && value >= 1 && value <= 9) slot = &h->splitk_min_steps;

@@ -1309,215 +1309,6 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
     else conv_epilogue_b<NT, 0, TH, 0, false>(a, o, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
 }
 
-// k_conv_wino<1> with TWO workgroups per CU, for launches that give every CU several tiles of a 32-column layer.
-// Why: k_conv_wino holds all 16 positions of a (32 windows x 32 channels) wave tile = 256 accumulator registers, so a CU runs ONE
-// workgroup, and nothing overlaps a tile's prologue (kernel arguments, addresses, first DMA, first transform: ~10 k cycles) and
-// epilogue (output transform, BN / ReLU / pool / head, stores: ~8 k) -- on the 256x256 layers with 32 / 64 input channels that is
-// as long as the 4 - 8 chunks of MFMAs in between (measured: 0.40 - 0.53 of the matrix pipe).  Here a wave holds HALF the
-// positions (128 accumulators), so two workgroups share a CU and one's prologue / transform / epilogue runs under the other's
-// MFMAs:  tile 16x16 pixels = 64 windows x 32 channels; wave (sub, ph) = windows of rows 4 sub .. 4 sub + 3, positions
-// 8 ph .. 8 ph + 7.  After the chunk loop the ph = 1 waves hand their accumulators to their ph = 0 partners through LDS (same
-// lane = same window and channel), which then run k_conv_wino's output transform and the shared epilogue.  Every V entry, every
-// U entry and every MFMA sequence is k_conv_wino<1>'s, so the result is bit-identical to it (tests/test_gpu_invariance.py).
-//   LDS 76 KB: raw 18x18-pixel halo of an 8-channel chunk (12 KB incl. DMA padding) | V [16][64 windows][32 B] (32 KB) |
-//   U ring: 2 chunks x 16 positions x [32 cout][32 B] (2 x 16 KB).  Two barriers per chunk; the other workgroup fills the gaps.
-template <int NT>
-__global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs a) {
-    static_assert(NT == 1, "the 64-column layers would need 512 threads per workgroup at 128 accumulators per wave");
-    constexpr int PB = 32;                          // bytes of one pixel's / window's / output channel's 8-channel chunk row
-    constexpr int SL = 2;
-    constexpr int TH = 16;
-    constexpr int RP = 18;
-    constexpr int RAW_PIX = (TH + 2) * RP;
-    constexpr int RAW_PIECES = RAW_PIX * SL;        // 648
-    constexpr int RAW_IT = (RAW_PIECES + 255) / 256;   // 3
-    constexpr int RAW_PAD = RAW_IT * 4096;          // every lane of every DMA instruction lands inside the buffer
-    constexpr int VP = 64 * PB;                     // bytes of one position's V: 2048
-    constexpr int V_BYTES = 16 * VP;
-    constexpr int UP_BYTES = 32 * PB;               // one position's weights: 1024
-    constexpr int UC_BYTES = 16 * UP_BYTES;         // one chunk's: 16 KB = 4 DMA instructions per wave
-    constexpr int VB = RAW_PAD, UB = RAW_PAD + V_BYTES;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sub = wave & 1, ph = wave >> 1;
-    const int li = lane & 31, lh = lane >> 5;
-
-    const int bz = (int)blockIdx.z;
-    const int gz = a.zdiv << a.zgroup_shift;
-    const int q_ = (gz == 1) ? bz : (int)(((float)bz + 0.5f) * a.zrcp);
-    const int rz = bz - q_ * gz;
-    const int n_tile = rz >> a.zgroup_shift;
-    const int b = (q_ << a.zgroup_shift) + (rz & ((1 << a.zgroup_shift) - 1));
-    if (b >= a.frames) return;
-    const int ty0 = (int)blockIdx.y * TH, tx0 = (int)blockIdx.x * 16;
-
-    const og_i32x4 in_rsrc = og_make_rsrc(a.in + (long long)b * a.in_frame_stride + a.in_ch_off,
-                                          (unsigned)(a.in_frame_stride - a.in_ch_off) * 4u);
-    const unsigned lds0 = og_lds_addr(smem);
-    const int n_ck = a.n_chunks * 4;
-    const og_i32x4 w_rsrc = og_make_rsrc(a.wpk + (long long)n_tile * n_ck * (UC_BYTES / 4), (unsigned)n_ck * (unsigned)UC_BYTES);
-    auto stage_u = [&](int ck) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + UB + (unsigned)((ck & 1) * UC_BYTES) + wave * 1024);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16b((unsigned)tid * 16u, w_rsrc, (unsigned)(ck * UC_BYTES + i * 4096), base + i * 4096);
-    };
-    stage_u(0);   // needs no per-lane address: in flight while the halo offsets are computed
-    unsigned hoff[RAW_IT];   // as k_conv_wino: pixel (hy, hx) at index hy * RP + (hx & 1) * 9 + (hx >> 1), SL pieces of 16 B
-#pragma unroll
-    for (int it = 0; it < RAW_IT; ++it) {
-        const int id = it * 256 + tid;
-        const int p = id / SL, pc = id % SL;
-        const int hy = p / RP, r = p - hy * RP;
-        const int hx = (r >= 9) ? 2 * (r - 9) + 1 : 2 * r;
-        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-        const bool inb = id < RAW_PIECES && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        hoff[it] = inb ? (unsigned)((gy * a.W + gx) * a.in_pix_stride * 4 + pc * 16) : OG_OOB;
-    }
-    auto stage_raw = [&](int ck) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
-#pragma unroll
-        for (int it = 0; it < RAW_IT; ++it) glds16b(hoff[it], in_rsrc, (unsigned)ck * PB, base + it * 4096);
-    };
-    stage_raw(0);
-
-    // fragments: k_conv_wino<1>'s addressing with wm = sub and a position's V block of 2 KB
-    const int wxa = 2 * (li >> 3) + ((li >> 2) & 1);
-    const unsigned abase = lds0 + VB + (unsigned)(8 * ph * VP) +
-                           (unsigned)((8 * (4 * sub + (wxa >> 1)) + (li & 3) + 4 * (wxa & 1)) * 32 + ((lh ^ ((wxa >> 1) & 1)) << 4));
-    const unsigned bbase = lds0 + UB + (unsigned)(8 * ph * UP_BYTES) + (unsigned)(li * 32 + ((lh ^ ((li >> 3) & 1)) << 4));
-    // transform role: item = (window, 16-byte piece), half h of the positions (rows 2h, 2h + 1 of the position grid)
-    const int it_ = tid & 127, h = __builtin_amdgcn_readfirstlane(tid >> 7);
-    const int qc = it_ & 1;
-    const int wr = ((it_ >> 2) & 3) + 4 * ((it_ >> 6) & 1);
-    const int wc = ((it_ >> 1) & 1) + 2 * ((it_ >> 4) & 3);
-    const unsigned rbase = lds0 + (unsigned)(((2 * wr + h) * RP + wc) * PB + qc * 16);      // patch rows h .. h + 2
-    const unsigned vwbase = lds0 + VB + (unsigned)(8 * h * VP) +
-                            (unsigned)((8 * (4 * (wr >> 2) + (wc >> 1)) + (wr & 3) + 4 * (wc & 1)) * 32 + ((qc ^ ((wc >> 1) & 1)) << 4));
-
-    auto transform = [&]() {   // raw -> V[8h .. 8h + 7]: rows 2h, 2h + 1 of B^T d B, exactly k_conv_wino's row_op / col_op
-        f32x4 t[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned o_ = (unsigned)(((j & 1) * 9 + (j >> 1)) * PB);
-            const f32x4 A = og_lds_read16(rbase + o_), B = og_lds_read16(rbase + o_ + RP * PB), C = og_lds_read16(rbase + o_ + 2 * RP * PB);
-            if (h == 0) {   // patch rows 0, 1, 2:  t0 = d0 - d2,  t1 = d1 + d2
-                t[j] = A - C;
-                t[4 + j] = B + C;
-            } else {        // patch rows 1, 2, 3:  t2 = d2 - d1,  t3 = d1 - d3
-                t[j] = B - A;
-                t[4 + j] = A - C;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const f32x4 c0 = t[4 * i + 0] - t[4 * i + 2], c1 = t[4 * i + 1] + t[4 * i + 2], c2 = t[4 * i + 2] - t[4 * i + 1],
-                        c3 = t[4 * i + 1] - t[4 * i + 3];
-            *(OG_LDS_AS f32x4*)(unsigned long long)(vwbase + (unsigned)((4 * i + 0) * VP)) = c0;
-            *(OG_LDS_AS f32x4*)(unsigned long long)(vwbase + (unsigned)((4 * i + 1) * VP)) = c1;
-            *(OG_LDS_AS f32x4*)(unsigned long long)(vwbase + (unsigned)((4 * i + 2) * VP)) = c2;
-            *(OG_LDS_AS f32x4*)(unsigned long long)(vwbase + (unsigned)((4 * i + 3) * VP)) = c3;
-        }
-    };
-
-    f32x16 acc[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-
-    og_wait_dma();
-    __syncthreads();
-    for (int c = 0; c < n_ck; ++c) {
-        transform();
-        __syncthreads();   // V complete; the raw buffer and U[(c + 1) & 1] (multiplied an iteration ago) are free
-        if (c + 1 < n_ck) {
-            stage_raw(c + 1);
-            stage_u(c + 1);
-        }
-        const unsigned uo = (unsigned)((c & 1) * UC_BYTES);
-        f32x4 fa[2], fb[2];
-        fa[0] = og_lds_read16(abase);
-        fb[0] = og_lds_read16(bbase + uo);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (k + 1 < 8) {
-                fa[(k + 1) & 1] = og_lds_read16(abase + (unsigned)((k + 1) * VP));
-                fb[(k + 1) & 1] = og_lds_read16(bbase + uo + (unsigned)((k + 1) * UP_BYTES));
-            }
-            const f32x4 av = fa[k & 1], bv = fb[k & 1];
-            __builtin_amdgcn_sched_barrier(0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[k], 0, 0, 0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[k], 0, 0, 0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[k], 0, 0, 0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[k], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        og_wait_dma();
-        __syncthreads();   // chunk c + 1 has landed for every wave; V is free
-    }
-
-    // ---- hand-over through LDS (V and the U ring are dead: 64 KB).  The output transform of accumulator register r = 4q + e needs
-    //      register r of ALL 16 positions and yields sub-tile (pixel-row pair) e; the wave pair splits the sub-tiles: ph = 0 keeps
-    //      e = 0, 1 and ph = 1 keeps e = 2, 3, each sends the partner the other two registers of its own 8 positions (64 registers
-    //      per lane each way; same lane = same window and channel in both waves), so that all four waves share the epilogue ----
-    const unsigned ex_out = lds0 + VB + (unsigned)(wave * 16384) + (unsigned)lane * 16u;                 // this wave's outbox
-    const unsigned ex_in = lds0 + VB + (unsigned)((wave ^ 2) * 16384) + (unsigned)lane * 16u;            // the partner's
-    const int es = 2 * (1 - ph);   // first register (mod 4) this wave gives away: ph 0 sends e = 2, 3; ph 1 sends e = 0, 1
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int q = 0; q < 4; q += 2) {   // two quarters per 16-byte store: {r = 4q + es, 4q + es + 1, 4(q+1) + es, 4(q+1) + es + 1}
-            const f32x4 v = ph ? f32x4{acc[k][4 * q], acc[k][4 * q + 1], acc[k][4 * q + 4], acc[k][4 * q + 5]}
-                               : f32x4{acc[k][4 * q + 2], acc[k][4 * q + 3], acc[k][4 * q + 6], acc[k][4 * q + 7]};
-            *(OG_LDS_AS f32x4*)(unsigned long long)(ex_out + (unsigned)((k * 2 + (q >> 1)) * 1024)) = v;
-        }
-    (void)es;
-    __syncthreads();
-    const int ecol = n_tile * 32 + li;
-    const float esc = a.scale[ecol], esh = a.shift[ecol];
-    f32x16 o[2];
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {   // quarters 2qq, 2qq + 1
-        f32x4 theirs[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) theirs[k] = og_lds_read16(ex_in + (unsigned)((k * 2 + qq) * 1024));
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            const int q = 2 * qq + qi;
-#pragma unroll
-            for (int el = 0; el < 2; ++el) {   // kept register e = 2 ph + el  ->  sub-tile el of this wave
-                float m[16];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float own = ph ? acc[k][4 * q + 2 + el] : acc[k][4 * q + el];
-                    const float got = theirs[k][2 * qi + el];
-                    m[8 * ph + k] = own;          // positions 8 ph .. 8 ph + 7 are this wave's
-                    m[8 * (1 - ph) + k] = got;
-                }
-                float tm[2][4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {   // Y = A^T M A exactly as k_conv_wino writes it
-                    tm[0][j] = m[0 + j] + m[4 + j] + m[8 + j];
-                    tm[1][j] = m[4 + j] - m[8 + j] - m[12 + j];
-                }
-#pragma unroll
-                for (int y = 0; y < 2; ++y) {
-                    o[el][4 * q + 2 * y + 0] = tm[y][0] + tm[y][1] + tm[y][2];
-                    o[el][4 * q + 2 * y + 1] = tm[y][1] - tm[y][2] - tm[y][3];
-                }
-            }
-        }
-    }
-    __syncthreads();   // every inbox has been read: the epilogue's per-wave scratch (20 KB from the start of LDS) runs into the hand-over area
-    // sub-tiles (pixel-row pairs) 2 (2 sub + ph) and + 1 of the tile: the shared epilogue with two sub-tiles per wave
-    unsigned char* const scr = smem + wave * 5120;
-    if (a.act == 1) conv_epilogue_b<1, 0, TH, 1, false, false, 2>(a, o, n_tile, b, ty0, tx0, 2 * sub + ph, 0, li, lh, esc, esh, scr);
-    else conv_epilogue_b<1, 0, TH, 0, false, false, 2>(a, o, n_tile, b, ty0, tx0, 2 * sub + ph, 0, li, lh, esc, esh, scr);
-}
-
 // 16-byte device-scope (sc1: written through / read past this XCD's L2) store and load for the exchange of raw accumulators
 // between workgroups that may sit on different XCDs -- the 128-bit form of what __hip_atomic_store / __hip_atomic_load at agent
 // scope compile to (global_store_dword ... sc1).  The store is followed by one wait state for the same reason as

@@ -98,7 +98,7 @@ def test_bench_configuration_against_reference_fixture(setup):
     # the chain really is the bench's: the Winograd kernel on the fourteen 64-column and the three 32-column 3x3 layers, fused head
     prof = m.profile(fdev, 64, 256, 256, reps=1)
     kernels = [p["kernel"] for p in prof]
-    assert kernels.count(DOMINANT) == 14 and kernels.count("k_conv_wino2<1>") == 3, kernels   # + the three 32-column layers (two workgroups per CU)
+    assert kernels.count(DOMINANT) == 14 and kernels.count("k_conv_wino<1>") == 3, kernels   # + the three 32-column layers
     assert kernels[0] == "k_conv_first<u8>" and "k_head" not in kernels, kernels                # first layer unfused, head fused
     assert all(k.startswith(("k_conv_mfma_o<2,1", "k_conv_wino", "k_conv_first")) for k in kernels), kernels
     # the direct form of the same chain (option "wino" 0) against the
@@ -178,7 +178,7 @@ def test_trained_full_width_net_exact_in_bench_configuration(golden_dir):
         d = np.array([og.dice(mk[i], gt[i]) for i in range(n)])
         assert np.abs(d - g["dice_vs_gt"]).max() <= 1e-12
     kernels = [p["kernel"] for p in m.profile(fdev, 64, 256, 256, reps=1)]
-    assert kernels.count("k_conv_wino<2>") == 14 and kernels.count("k_conv_wino2<1>") == 3, kernels
+    assert kernels.count("k_conv_wino<2>") == 14 and kernels.count("k_conv_wino<1>") == 3, kernels
     # the reference's per-frame call pattern and the streamed frame loop give the same integers (one-frame launches run the
     # position-split kernels: same sums)
     from openglottal_amd.features import area_waveform

@@ -130,8 +130,6 @@ def test_same_kernels_at_every_micro_batch_size(base):
         assert "splitK" not in kernel, kernel
         if kernel.startswith("k_conv_wino_ps<"):     # position-split launch of the same form (same sums, more workgroups)
             return "k_conv_wino<" + kernel.split("<")[1].split(",")[0] + ">"
-        if kernel == "k_conv_wino2<1>":              # two-workgroups-per-CU launch of the same form
-            return "k_conv_wino<1>"
         return kernel if kernel.startswith(("k_conv_wino", "k_conv_first")) else "direct:" + kernel.split("<")[1].split(",")[1]   # MODE
 
     k64 = [(p["layer"], form(p["kernel"])) for p in m.profile(d, 64, 256, 256, reps=1)]
@@ -141,26 +139,6 @@ def test_same_kernels_at_every_micro_batch_size(base):
     names = [k for _, k in k64]
     assert names.count("k_conv_wino<2>") == 14 and names.count("k_conv_wino<1>") == 3, names
     assert not any("splitK" in k for k in names), names
-
-
-def test_two_workgroups_per_cu_kernel_is_bit_identical(base):
-    """k_conv_wino2<1> (chip-filling launches of the 32-column layers: half the positions per wave, LDS hand-over) against
-    k_conv_wino<1> ("wino2" 0) on 96 frames, logits bit for bit, and really taken by default."""
-    import torch
-
-    m, fr, masks, areas, logits = base
-    n = 96
-    names = [p["kernel"] for p in m.profile(torch.from_numpy(fr[:64]).to("cuda:0"), 64, 256, 256, reps=1)]
-    assert names.count("k_conv_wino2<1>") == 3, names
-    try:
-        m.set_option("wino2", 0)
-        names = [p["kernel"] for p in m.profile(torch.from_numpy(fr[:64]).to("cuda:0"), 64, 256, 256, reps=1)]
-        assert names.count("k_conv_wino<1>") == 3 and "k_conv_wino2<1>" not in names, names
-        mk, ar, lg = m.segment(fr[:n], want_logits=True)
-        assert np.array_equal(lg, logits[:n]), float(np.abs(lg - logits[:n]).max())
-        assert np.array_equal(ar, areas[:n]) and np.array_equal(mk, masks[:n])
-    finally:
-        m.set_option("wino2", 1)
 
 
 def test_position_split_launches_are_bit_identical(base):
