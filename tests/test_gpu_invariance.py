@@ -170,6 +170,37 @@ def test_position_split_launches_are_bit_identical(base):
         m.set_chunk(64)
 
 
+@pytest.mark.parametrize("feats,shape", [((32, 64), (128, 256)), ((32, 64), (96, 160)), ((64, 128), (48, 64)), ((40, 80), (64, 64)),
+                                         ((32, 64, 128), (64, 32)), ((32, 64), (256, 128))])
+def test_position_split_on_other_shapes(feats, shape):
+    """The position-split launches on other widths, depths and frame shapes (maps of 1 to 10 tiles across, padded channel slots,
+    32- and 64-column layers, layers that fall back to the direct kernel): every forced PN and the automatic choice against
+    k_conv_wino, at one, two and five frames per chain -- logits bit for bit; and the canonical result against the oracle."""
+    import torch
+    from oracle import unet_oracle as O
+
+    H, W = shape
+    sd = synth.make_unet_state_dict(feats, seed=H * 7 + W + len(feats), head_scale=2.0, head_bias=-0.4)
+    m = og.UNet(1, 1, feats)
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    fr = synth.random_gray_frames(5, H, W, seed=H + W)
+    m.set_option("wino_ps", 0)
+    m.set_chunk(5)
+    _, a0, l0 = m.segment(fr, want_mask=False, want_logits=True)
+    ref_mask, ref_logits = O.segment_frames(sd, fr[:2], backend="torch")
+    assert np.abs(l0[:2] - ref_logits).max() <= 5e-5 * max(1.0, float(np.abs(ref_logits).max()))
+    seen = 0
+    for ps in (1, 2, 3, 4):
+        m.set_option("wino_ps", ps)
+        for chunk in (1, 2, 5):
+            m.set_chunk(chunk)
+            _, a1, l1 = m.segment(fr, want_mask=False, want_logits=True)
+            assert np.array_equal(l1, l0) and np.array_equal(a1, a0), (ps, chunk, float(np.abs(l1 - l0).max()))
+        seen += sum(p["kernel"].startswith("k_conv_wino_ps") for p in m.profile(torch.from_numpy(fr[:1]).to("cuda:0"), 1, H, W, reps=1))
+    assert seen > 0     # the split kernels really ran on this shape
+
+
 def _rank(rank, world, port, q):
     import torch.distributed as dist
 
