@@ -1159,10 +1159,12 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
         asm volatile("" : "+v"(bbase[j]));
     }
     // transform role: window (row wr, column wc), channels 4 qc .. 4 qc + 3 of the chunk
-    // (NT 1: lane bits = quad, column bit 0, row bits 1:0, column bits 2:1, so that the 16 lanes of a V write cover 16 bank groups)
+    // (NT 1: lane bits = quad, row bits 1:0, column bit 0, column bits 2:1: the 8 lanes of a ds_write_b128 service group then write
+    //  128 contiguous bytes of V (round 2's order -- column bit 0 below the row bits -- put lanes 0-3 and 4-7 on the same 32 banks:
+    //  2.2e7 SQ_LDS_BANK_CONFLICT cycles per launch, all from these writes), and the 16-lane groups of the raw reads stay conflict-free)
     const int qc = tid % SL;
-    const int wr = (NT == 2) ? (tid >> 5) : 4 * (tid >> 6) + ((tid >> 2) & 3);
-    const int wc = (NT == 2) ? ((tid >> 2) & 7) : ((tid >> 1) & 1) + 2 * ((tid >> 4) & 3);
+    const int wr = (NT == 2) ? (tid >> 5) : 4 * (tid >> 6) + ((tid >> 1) & 3);
+    const int wc = (NT == 2) ? ((tid >> 2) & 7) : ((tid >> 3) & 1) + 2 * ((tid >> 4) & 3);
     const int wt = 8 * wr + wc;
     unsigned rbase = lds0 + (unsigned)((2 * wr * RP + wc) * PB + qc * 16);
     unsigned vwbase = (NT == 2) ? lds0 + RAW_BYTES + (unsigned)(wt * 64 + ((qc ^ (wr & 3)) << 4))
@@ -1433,8 +1435,8 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_ps(ConvArgs a) {
         }
     }
     const int qc = tid % SL;
-    const int wr = (NT == 2) ? (tid >> 5) : 4 * (tid >> 6) + ((tid >> 2) & 3);
-    const int wc = (NT == 2) ? ((tid >> 2) & 7) : ((tid >> 1) & 1) + 2 * ((tid >> 4) & 3);
+    const int wr = (NT == 2) ? (tid >> 5) : 4 * (tid >> 6) + ((tid >> 1) & 3);
+    const int wc = (NT == 2) ? ((tid >> 2) & 7) : ((tid >> 3) & 1) + 2 * ((tid >> 4) & 3);
     const int wt = 8 * wr + wc;
     const unsigned rbase = lds0 + (unsigned)((2 * wr * RP + wc) * PB + qc * 16);
     const unsigned vwbase = (NT == 2) ? lds0 + VB + (unsigned)(wt * 64 + ((qc ^ (wr & 3)) << 4))

@@ -1,5 +1,5 @@
 import os, sys, time, itertools
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import openglottal_amd as og
 from openglottal_amd import synth
