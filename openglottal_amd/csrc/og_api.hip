@@ -546,8 +546,7 @@ constexpr int wino_lds() { return (32 / NT + 2) * 18 * (32 * NT) + 16 * 4096 + 2
 
 template <int NT>
 int launch_conv_wino(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {   // 16x16 (NT 2) / 32x16 (NT 1) pixel tiles, one workgroup per CU
-    ConvArgs a = a_in;
-    a.stamps = nullptr;
+    ConvArgs a = a_in;   // (a.stamps: diagnostic timeline, 8 x u64 for the first 511 workgroups)
     a.ksplit = 1;
     a.tile_counter = nullptr;
     const int frames = a.n_spatial / (a.tiles_x * a.tiles_y);

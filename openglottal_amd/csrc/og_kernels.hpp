@@ -1106,6 +1106,13 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
     const int b = (q_ << a.zgroup_shift) + (rz & ((1 << a.zgroup_shift) - 1));
     if (b >= a.frames) return;
     const int ty0 = (int)blockIdx.y * TH, tx0 = (int)blockIdx.x * 16;
+    // diagnostic timeline (og_unet_clock_probe only; nullptr on every product path): 8 stamps for the first 511 workgroups
+    unsigned long long* st = nullptr;
+    if (a.stamps != nullptr) {
+        const unsigned wg = ((unsigned)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        st = a.stamps + 8ull * (wg < 511u ? wg : 511u);
+        if (tid == 0) st[0] = __builtin_amdgcn_s_memtime();
+    }
 
     const og_i32x4 in_rsrc = og_make_rsrc(a.in + (long long)b * a.in_frame_stride + a.in_ch_off,
                                           (unsigned)(a.in_frame_stride - a.in_ch_off) * 4u);
@@ -1138,6 +1145,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
     for (int it = 0; it < RAW_IT; ++it) raw_piece(0, it);
 #pragma unroll
     for (int i = 0; i < U_IT; ++i) u_piece(0, 0, i);
+    if (st != nullptr && tid == 0) st[1] = __builtin_amdgcn_s_memtime();   // first DMAs issued
 
     // Fragment addressing.  MFMA row i of a wave = window (row 4 wm + (i & 3), column wx = 2 (i >> 3) + ((i >> 2) & 1)).
     // NT 2: window w's 64-B row at w * 64, slot s at s ^ (w >> 3 & 3): the 16 lanes of a read hit 16 distinct 16-B bank groups.
@@ -1177,9 +1185,13 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
 
     f32x16 acc[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
+    for (int k = 0; k < 16; ++k) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+        // pin the 256 v_accvgpr_write of the zeroing HERE, under the latency of the first DMAs: hipcc otherwise sinks them to the
+        // first MFMA, i.e. into the main loop of the first chunk (timeline: the first halo takes 1.3 - 9 k cycles to land)
+        asm volatile("" : "+a"(acc[k]));
+    }
 
     // One wave per SIMD: nothing but this wave's own instruction stream can fill the matrix pipe's shadow, so everything that
     // is not an MFMA is cut into micro-ops and issued between the four MFMAs of a step (64 cycles each), in a fixed order:
@@ -1213,12 +1225,14 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
     auto xf4 = [&](int n) { xf_op(n); xf_op(n + 1); xf_op(n + 2); xf_op(n + 3); };
 
     og_wait_dma();
+    if (st != nullptr && tid == 0) st[2] = __builtin_amdgcn_s_memtime();   // first halo and weight group landed
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < 48; ++n) xf_op(n);
 #pragma unroll
     for (int k = 0; k < 8; ++k) v_write(k);
     __syncthreads();   // lo half of V (chunk 0) complete; every read of the raw buffer done
+    if (st != nullptr && tid == 0) st[3] = __builtin_amdgcn_s_memtime();   // main loop starts
 
     for (int c = 0; c < n_ck; ++c) {
         const bool nxt = c + 1 < n_ck;
@@ -1290,6 +1304,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
         }
     }
 
+    if (st != nullptr && tid == 0) st[4] = __builtin_amdgcn_s_memtime();   // main loop done
     // ---- output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1], in registers; then the shared epilogue ----
     f32x16 o[4];
 #pragma unroll
@@ -1306,9 +1321,15 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
             o[r & 3][4 * (r >> 2) + 2 * y + 1] = tm[y][1] - tm[y][2] - tm[y][3];
         }
     }
+    if (st != nullptr && tid == 0) st[5] = __builtin_amdgcn_s_memtime();   // output transform done (wave 0)
     unsigned char* const scr = smem + wave * 5120;   // the raw buffer is dead (>= 19 KB; the epilogue's scratch runs into V, dead too)
     if (a.act == 1) conv_epilogue_b<NT, 0, TH, 1, false>(a, o, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
     else conv_epilogue_b<NT, 0, TH, 0, false>(a, o, n_tile, b, ty0, tx0, wm, wn, li, lh, esc, esh, scr);
+    if (st != nullptr && tid == 0) {
+        st[6] = __builtin_amdgcn_s_memtime();                               // epilogue issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st[7] = __builtin_amdgcn_s_memtime();                               // stores acknowledged
+    }
 }
 
 // 16-byte device-scope (sc1: written through / read past this XCD's L2) store and load for the exchange of raw accumulators

@@ -24,6 +24,36 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     assert b"gfx950" in lib.og_version()
+    assert b"store_nop=1" in lib.og_version()     # a production build: the loader refuses anything else (next test)
+
+
+def test_loader_refuses_an_audit_build(monkeypatch):
+    """`_lib.lib()` must not hand out a library whose `og_version()` lacks the store-nop marker (the -DOG_STORE_NOP=0 audit build of
+    tools/epilogue_fence_audit.sh computes wrong lanes); only OPENGLOTTAL_HIP_ALLOW_AUDIT_BUILD=1 lets it through."""
+    import ctypes as C
+
+    from openglottal_amd import _lib
+
+    real = _lib.lib()
+
+    class FakeFn:
+        def __init__(self, fn):
+            self._fn = fn
+        def __call__(self, *a):
+            return b"openglottal_hip 0.3 (gfx950; store_nop=0)"
+
+    class Fake:
+        def __getattr__(self, name):
+            return FakeFn(None) if name == "og_version" else getattr(real, name)
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(C, "CDLL", lambda path: Fake())
+    monkeypatch.delenv("OPENGLOTTAL_HIP_ALLOW_AUDIT_BUILD", raising=False)
+    with pytest.raises(_lib.OpenGlottalHipError, match="not a production build"):
+        _lib.lib()
+    monkeypatch.setenv("OPENGLOTTAL_HIP_ALLOW_AUDIT_BUILD", "1")
+    assert _lib.lib() is not None
+    monkeypatch.setattr(_lib, "_lib", real)
 
 
 def test_no_cpu_fallback():
