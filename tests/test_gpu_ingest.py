@@ -233,3 +233,41 @@ def test_mixed_frame_sizes_reuse_the_arena_and_give_the_same_results(trained):
         assert np.array_equal(mk, mk2) and np.array_equal(ar, ar2) and np.array_equal(lg, lg2), s
     assert np.array_equal(got[0][1].astype(np.int64), g["areas"][:20])
     m.set_chunk(32)
+
+
+def test_frame_list_entry_equals_the_stacked_video(trained):
+    """`og_unet_stream_frames_u8` (a LIST of separately allocated frames, as the reference's `frames_bgr`): masks, areas and
+    box-gated areas equal those of the same video as one array -- gray and BGR, non-contiguous / non-u8 items converted,
+    ragged over the micro-batch, one frame, empty list; mismatched shapes and null entries refused."""
+    import ctypes as C
+
+    from openglottal_amd._lib import lib
+
+    g, m, frames = trained
+    n = 37
+    gray = frames[:n]
+    rs = np.random.RandomState(3)
+    bgr = np.clip(gray[..., None].astype(np.int32) + rs.randint(-4, 5, (n, 256, 256, 3)), 0, 255).astype(np.uint8)
+    boxes = np.array([normalize_box((30 + i, 40, 200 - i, 220), 256, 256) for i in range(n)], np.int32)
+    boxes[5] = -1
+    m.set_chunk(16)
+    try:
+        for video in (gray, bgr):
+            mk_a, ar_a = m.segment_stream(video, boxes=boxes, want_mask=True)
+            items = [np.array(f) for f in video]                                     # separately allocated
+            items[3] = np.asfortranarray(items[3]) if items[3].ndim == 2 else items[3][:, ::-1][:, ::-1]   # a non-contiguous view
+            items[4] = items[4].astype(np.int32)                                     # a non-u8 item
+            mk_l, ar_l = m.segment_stream(items, boxes=boxes, want_mask=True)
+            assert np.array_equal(ar_l, ar_a) and np.array_equal(mk_l, mk_a)
+            mk_1, ar_1 = m.segment_stream(items[:1], want_mask=True)
+            assert np.array_equal(mk_1[0], m.segment_stream(video[:1], want_mask=True)[0][0])
+        mk_e, ar_e = m.segment_stream([], want_mask=True)
+        assert ar_e.shape == (0,)
+        with pytest.raises(og.OpenGlottalHipError):
+            m.segment_stream([gray[0], gray[1][:128]])
+        ptrs = (C.c_void_p * 2)(gray[0].ctypes.data, None)
+        area = np.zeros(2, np.int32)
+        assert lib().og_unet_stream_frames_u8(m._h, ptrs, 2, 256, 256, 1, C.c_float(0.5), None, None, area.ctypes.data_as(C.c_void_p)) != 0
+        assert b"frame_ptrs[1]" in lib().og_last_error()
+    finally:
+        m.set_chunk(32)
