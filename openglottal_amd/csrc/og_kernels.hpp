@@ -1119,15 +1119,21 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
     // raw halo image: pixel (hy, hx) at index hy * RP + (hx & 1) * 9 + (hx >> 1) (even and odd columns apart: the windows of
     // a row then read consecutive pixels), SL pieces of 16 B per pixel
     unsigned hoff[RAW_IT];
+    {   // piece id = it * 256 + tid walks in steps of 256 pieces = 256 / SL pixels = QY rows + QR pixels of the RP-pixel image rows: one
+        // division for the first piece, then adds (each constant division is ~5 vector-ALU instructions on the way to the first DMA)
+        constexpr int QY = (256 / SL) / RP, QR = (256 / SL) % RP;
+        const int pc = tid % SL;
+        int hy = (tid / SL) / RP, r = (tid / SL) - hy * RP;
 #pragma unroll
-    for (int it = 0; it < RAW_IT; ++it) {
-        const int id = it * 256 + tid;
-        const int p = id / SL, pc = id % SL;
-        const int hy = p / RP, r = p - hy * RP;
-        const int hx = (r >= 9) ? 2 * (r - 9) + 1 : 2 * r;
-        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-        const bool inb = id < RAW_PIECES && r < 18 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        hoff[it] = inb ? (unsigned)((gy * a.W + gx) * a.in_pix_stride * 4 + pc * 16) : OG_OOB;
+        for (int it = 0; it < RAW_IT; ++it) {
+            const int hx = (r >= 9) ? 2 * (r - 9) + 1 : 2 * r;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            const bool inb = it * 256 + tid < RAW_PIECES && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            hoff[it] = inb ? (unsigned)((gy * a.W + gx) * a.in_pix_stride * 4 + pc * 16) : OG_OOB;
+            hy += QY;
+            r += QR;
+            if (r >= RP) { r -= RP; hy += 1; }
+        }
     }
     const bool last_valid = ((RAW_IT - 1) * 256 + tid) < RAW_PIECES;
     const unsigned lds0 = og_lds_addr(smem);
@@ -1415,15 +1421,20 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_ps(ConvArgs a) {
     const og_i32x4 in_rsrc = og_make_rsrc(a.in + (long long)b * a.in_frame_stride + a.in_ch_off,
                                           (unsigned)(a.in_frame_stride - a.in_ch_off) * 4u);
     unsigned hoff[RAW_IT];   // as k_conv_wino: pixel (hy, hx) at index hy * RP + (hx & 1) * 9 + (hx >> 1)
+    {   // incremental walk of the piece id, as in k_conv_wino
+        constexpr int QY = (256 / SL) / RP, QR = (256 / SL) % RP;
+        const int pc = tid % SL;
+        int hy = (tid / SL) / RP, r = (tid / SL) - hy * RP;
 #pragma unroll
-    for (int it = 0; it < RAW_IT; ++it) {
-        const int id = it * 256 + tid;
-        const int p = id / SL, pc = id % SL;
-        const int hy = p / RP, r = p - hy * RP;
-        const int hx = (r >= 9) ? 2 * (r - 9) + 1 : 2 * r;
-        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-        const bool inb = id < RAW_PIECES && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        hoff[it] = inb ? (unsigned)((gy * a.W + gx) * a.in_pix_stride * 4 + pc * 16) : OG_OOB;
+        for (int it = 0; it < RAW_IT; ++it) {
+            const int hx = (r >= 9) ? 2 * (r - 9) + 1 : 2 * r;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            const bool inb = it * 256 + tid < RAW_PIECES && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            hoff[it] = inb ? (unsigned)((gy * a.W + gx) * a.in_pix_stride * 4 + pc * 16) : OG_OOB;
+            hy += QY;
+            r += QR;
+            if (r >= RP) { r -= RP; hy += 1; }
+        }
     }
     const unsigned lds0 = og_lds_addr(smem);
     const int n_ck = a.n_chunks * (32 / KC);
