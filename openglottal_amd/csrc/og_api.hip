@@ -70,6 +70,8 @@ struct GraphKey {
 struct og_unet {
     std::vector<int> features;
     int L = 0;
+    int device = 0;   // HIP device the handle lives on (current device of the thread that finalized it): every entry point makes it
+                      // the calling thread's current device, so a handle can be driven from any host thread (HIP's is per thread)
     std::map<std::string, HostTensor> host;
     std::map<std::string, std::vector<int64_t>> expected;
     bool finalized = false;
@@ -1195,6 +1197,7 @@ int check_range(og_unet* h) {
 int check_shape(og_unet* h, int B, int H, int W) {
     if (!h) return fail(OG_EINVAL, "null handle");
     if (!h->finalized) return fail(OG_ESTATE, "og_unet_finalize() has not been called");
+    HIPCHK(hipSetDevice(h->device));   // the caller may be another host thread than the one that built the handle
     if (B < 0 || H <= 0 || W <= 0) return fail(OG_EINVAL, "bad B/H/W");
     const int m = 1 << h->L;
     if (H % m || W % m)
@@ -1480,6 +1483,7 @@ int og_unet_finalize(og_unet* h) {
         HIPCHK(hipGetDevice(&dev));
         HIPCHK(hipGetDeviceProperties(&prop, dev));
         h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        h->device = dev;
     }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&h->ev0));
@@ -1571,6 +1575,7 @@ int og_unet_finalize(og_unet* h) {
         t->h_range = h->h_range;
         t->d_range = h->d_range;
         t->n_cu = h->n_cu;
+        t->device = h->device;
         prev->twin = t;
         prev = t;
         HIPCHK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
@@ -1652,6 +1657,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
 
 int og_unet_sync(og_unet* h) {
     if (!h || !h->stream) return fail(OG_ESTATE, "handle not finalized");
+    HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     return check_range(h);
 }
@@ -1889,6 +1895,7 @@ int og_unet_forward_f32(og_unet* h, const float* x, int B, int H, int W, float* 
 
 int og_mask_area_dev(og_unet* h, const uint8_t* mask, int B, int H, int W, const int32_t* boxes, int32_t* area) {
     if (!h || !h->finalized) return fail(OG_ESTATE, "handle not finalized");
+    HIPCHK(hipSetDevice(h->device));
     if (!mask || !area || B < 0 || H <= 0 || W <= 0) return fail(OG_EINVAL, "bad argument");
     if (B == 0) return OG_OK;
     HIPCHK(hipMemsetAsync(area, 0, (size_t)B * 4, h->stream));
@@ -1900,6 +1907,7 @@ int og_mask_area_dev(og_unet* h, const uint8_t* mask, int B, int H, int W, const
 
 int og_bgr2gray_dev(og_unet* h, const uint8_t* bgr, int B, int H, int W, uint8_t* gray) {
     if (!h || !h->finalized) return fail(OG_ESTATE, "handle not finalized");
+    HIPCHK(hipSetDevice(h->device));
     if (!bgr || !gray || B < 0 || H <= 0 || W <= 0) return fail(OG_EINVAL, "bad argument");
     const long long n = (long long)B * H * W;
     if (n == 0) return OG_OK;
@@ -1911,6 +1919,7 @@ int og_bgr2gray_dev(og_unet* h, const uint8_t* bgr, int B, int H, int W, uint8_t
 int og_canvas_letterbox_u8_dev(og_unet* h, const uint8_t* packed, const int64_t* offsets, const int32_t* shapes, int B, int channels,
                                int size, const int32_t* geom, int value, uint8_t* out) {
     if (!h || !h->finalized) return fail(OG_ESTATE, "handle not finalized");
+    HIPCHK(hipSetDevice(h->device));
     if (B < 0 || size <= 0 || (channels != 1 && channels != 3) || value < 0 || value > 255) return fail(OG_EINVAL, "bad argument");
     if (B == 0) return OG_OK;
     if (!packed || !offsets || !shapes || !geom || !out) return fail(OG_EINVAL, "null buffer");
@@ -1932,6 +1941,7 @@ int og_canvas_letterbox_u8_dev(og_unet* h, const uint8_t* packed, const int64_t*
 int og_canvas_letterbox_u8(og_unet* h, const uint8_t* packed, const int64_t* offsets, const int32_t* shapes, int B, int channels, int size,
                            const int32_t* geom, int value, uint8_t* out) {
     if (!h || !h->finalized) return fail(OG_ESTATE, "handle not finalized");
+    HIPCHK(hipSetDevice(h->device));
     if (B < 0 || size <= 0 || (channels != 1 && channels != 3)) return fail(OG_EINVAL, "bad argument");
     if (B == 0) return OG_OK;
     if (!packed || !offsets || !shapes || !geom || !out) return fail(OG_EINVAL, "null buffer");
@@ -1962,6 +1972,7 @@ int og_canvas_letterbox_u8(og_unet* h, const uint8_t* packed, const int64_t* off
 
 int og_mask_stats_dev(og_unet* h, const uint8_t* pred, const uint8_t* gt, int B, int H, int W, const int32_t* boxes, int32_t* stats) {
     if (!h || !h->finalized) return fail(OG_ESTATE, "handle not finalized");
+    HIPCHK(hipSetDevice(h->device));
     if (!pred || !gt || !stats || B < 0 || H <= 0 || W <= 0) return fail(OG_EINVAL, "bad argument");
     if (B == 0) return OG_OK;
     HIPCHK(hipMemsetAsync(stats, 0, (size_t)B * 12, h->stream));

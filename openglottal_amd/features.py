@@ -86,6 +86,7 @@ def load_frames_bgr(source) -> list[np.ndarray]:
 
 
 BLOCK = 1024  # frames handed to the device engine per call (host side only: the engine itself streams micro-batches)
+GATED_BLOCK = 128   # gated pipeline: the detector pass of block k + 1 runs (worker thread, own handle and stream) under the U-Net pass of block k
 
 
 def iter_frame_blocks(source, block: int = BLOCK):
@@ -124,6 +125,24 @@ def _detect_block(frames, detector) -> np.ndarray:
     return boxes
 
 
+def _blocks_with_boxes(frames, detector):
+    """``(block, boxes)`` pairs of the gated pipeline.  The detector network and the O(1)-per-frame temporal state machine of block
+    k + 1 run on ONE worker thread (so blocks are detected in order: the state machine is sequential, detector.py:61-96) while the
+    caller segments block k; both calls release the GIL inside the C-ABI.  Nothing about the results changes: same boxes, in the same
+    order, as a detect-everything-first pass."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    it = (b for b in iter_frame_blocks(frames, GATED_BLOCK) if len(b))
+    with ThreadPoolExecutor(1) as pool:
+        nxt = next(it, None)
+        fut = pool.submit(_detect_block, nxt, detector) if nxt is not None else None
+        while nxt is not None:
+            blk, boxes = nxt, fut.result()
+            nxt = next(it, None)
+            fut = pool.submit(_detect_block, nxt, detector) if nxt is not None else None
+            yield blk, boxes
+
+
 def area_waveform(frames, detector, model, device=None, threshold: float = 0.5) -> np.ndarray:
     """The frame loop of features.py:234-245 as batched device passes over blocks of the video.
 
@@ -138,11 +157,11 @@ def area_waveform(frames, detector, model, device=None, threshold: float = 0.5) 
         detector.reset()
     out = []
     done = 0
-    for blk in iter_frame_blocks(frames):
+    pairs = _blocks_with_boxes(frames, detector) if detector is not None else ((b, None) for b in iter_frame_blocks(frames))
+    for blk, boxes in pairs:
         n = len(blk)
         if n == 0:
             continue
-        boxes = _detect_block(blk, detector) if detector is not None else None
         shapes = {f.shape for f in blk}
         if len(shapes) == 1 and next(iter(shapes))[:2] == (NET_SIZE, NET_SIZE):
             # an array goes up in place; a list of frames (features.py:226's `frames_bgr`) is gathered by the engine itself,
