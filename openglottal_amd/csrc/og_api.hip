@@ -49,6 +49,7 @@ struct ConvLayer {  // one 3x3 conv + BN + ReLU, or one 2x2 transposed conv
     float* d_w_h = nullptr;   // the same weights as f16 hi/lo pairs in the H layout (opt-in split precision)
     float* d_w1 = nullptr;    // 3x3 convs with NT == 2: the same weights packed for 32-column tiles (split-K launches)
     float* d_ww = nullptr;    // 3x3 convs: Winograd F(2x2,3x3) image for k_conv_wino<NT> (pack_wino)
+    float* d_ww1 = nullptr;   // NT == 2 layers: the same image cut for 32-column tiles and 8-channel chunks (k_conv_wino_w)
     float* d_scale = nullptr;
     float* d_shift = nullptr;
 };
@@ -119,6 +120,8 @@ struct og_unet {
                          // (features.py:234-238 has no cross-frame state either).  0: the direct kernels for every layer.
     int wino_ps = 1;     // under-filled Winograd launches spread a tile's 16 positions over several workgroups (k_conv_wino_ps: bit-identical);
                          // 0 off, 1 auto, 2 / 3 / 4 force PN = 4 / 2 / 1 on every launch that qualifies
+    int wino_w = 1;      // under-filled Winograd launches on k_conv_wino_w (the 16 positions over the four waves of a workgroup, finer
+                         // tiles: bit-identical); 0 off, 1 auto, 2 / 3 force WB = 1 / 2 on every Winograd layer (tests, A/B)
     int wino_first = 1;  // Winograd chains: first layer unfused so that the second conv takes k_conv_wino<1>
     bool wino_chain = false;   // (pick_chain_form) wino && precision == 0 && conv_impl == 2
     int splitk_nt1 = 1;  // split 3x3 launches on 32-column tiles (twice the workgroups, half the MFMAs per K part)
@@ -329,6 +332,7 @@ int build_conv(og_unet* h, ConvLayer& L, const std::string& wkey, const std::str
     if ((rc = upload(pack_gemm_b_h(L.Cout_p, L.Cin_p, 9, L.NT, at), &L.d_w_h))) return rc;
     if (L.NT == 2 && (rc = upload(pack_gemm_b(L.Cout_p, L.Cin_p, 9, 1, at), &L.d_w1))) return rc;
     if ((rc = upload(pack_wino(L.Cout_p, L.Cin_p, L.NT, at), &L.d_ww))) return rc;
+    if (L.NT == 2 && (rc = upload(pack_wino(L.Cout_p, L.Cin_p, 1, at), &L.d_ww1))) return rc;
     if ((rc = upload(sc, &L.d_scale))) return rc;
     if ((rc = upload(sh, &L.d_shift))) return rc;
     return OG_OK;
@@ -375,9 +379,10 @@ void free_layer(ConvLayer& L) {
     if (L.d_w_h) (void)hipFree(L.d_w_h);
     if (L.d_w1) (void)hipFree(L.d_w1);
     if (L.d_ww) (void)hipFree(L.d_ww);
+    if (L.d_ww1) (void)hipFree(L.d_ww1);
     if (L.d_scale) (void)hipFree(L.d_scale);
     if (L.d_shift) (void)hipFree(L.d_shift);
-    L.d_w = L.d_w_h = L.d_w1 = L.d_ww = L.d_scale = L.d_shift = nullptr;
+    L.d_w = L.d_w_h = L.d_w1 = L.d_ww = L.d_ww1 = L.d_scale = L.d_shift = nullptr;
 }
 
 void drop_graphs(og_unet* h) {
@@ -593,6 +598,38 @@ int launch_conv_wino_ps(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) 
     return OG_OK;
 }
 
+template <int WB>
+constexpr int wino_w_lds() {
+    constexpr int raw_it = ((8 * WB + 2) * 18 * 8 + 255) / 256, ud = (WB == 1) ? 4 : 3;
+    return 2 * raw_it * 4096 + (ud + 1) * 16384;
+}
+
+// k_conv_wino_w: 8 WB x 16-pixel tiles x 32 output channels, the 16 positions over the four waves; a.tiles_y counts 8-row tiles
+// (the fused head's count slots), the grid has tiles_y / WB rows
+template <int WB>
+int launch_conv_wino_w(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
+    ConvArgs a = a_in;   // (a.stamps: per-workgroup timeline of diagnostic runs, 4 x u64 for up to 1024 workgroups)
+    a.ksplit = 1;
+    a.tile_counter = nullptr;
+    const int gy = a.tiles_y / WB;
+    const int frames = a.n_spatial / (a.tiles_x * a.tiles_y);
+    a.zdiv = n_ntiles;
+    a.frames = frames;
+    a.zgroup_shift = 0;
+    if (c.xcd_group && a.zdiv > 1) {
+        int txy = a.tiles_x * gy, g = 8;
+        while (g > 1 && txy % 2 == 0) { txy /= 2; g /= 2; }
+        while (g > frames) g /= 2;
+        while ((1 << a.zgroup_shift) < g) ++a.zgroup_shift;
+    }
+    const int G = 1 << a.zgroup_shift, groups = (frames + G - 1) / G;
+    a.zrcp = 1.0f / (float)(a.zdiv * G);
+    if ((long long)groups * G * a.zdiv > 65535) return fail(OG_EINVAL, "micro-batch too large for one launch (grid.z): lower the chunk size");
+    hipLaunchKernelGGL(k_conv_wino_w<WB>, dim3(a.tiles_x, gy, groups * G * a.zdiv), dim3(256), wino_w_lds<WB>(), c.stream, a);
+    HIPCHK(hipGetLastError());
+    return OG_OK;
+}
+
 template <int NT, int MODE, int TH, int OCC, bool SQ = false>
 int launch_conv_h(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {   // split-precision twin of launch_conv_o (no split-K)
     constexpr int lds = conv_o_lds<NT, MODE, TH>();
@@ -669,6 +706,8 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 16>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino<2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds<2>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds<1>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_w<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_w_lds<1>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_w<2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_w_lds<2>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_ps<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (wino_ps_lds<2, 1>())));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_ps<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (wino_ps_lds<2, 2>())));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_ps<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (wino_ps_lds<2, 4>())));
@@ -695,6 +734,22 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     if ((rc = set_conv_p_attr<2, 2, 8, 1>())) return rc;
     if ((rc = set_conv_p_attr<1, 2, 8, 1>())) return rc;
     return OG_OK;
+}
+
+// Which Winograd kernel runs a 3x3 layer that takes the Winograd form (decided by the caller from options and (H, W) alone):
+// 0 = k_conv_wino / k_conv_wino_ps, 1 / 2 = k_conv_wino_w<WB>.  All of them compute the same bits, so B may enter here.
+int pick_wino_w(const og_unet* h, const ConvLayer& L, int B, int H, int W) {
+    if (!h->wino_w || (L.NT == 2 && L.d_ww1 == nullptr) || H % 8 || W % 16) return 0;
+    if (h->wino_w == 2) return 1;
+    if (h->wino_w == 3) return (H % 16 == 0) ? 2 : 1;
+    const long long wgs_wino = (long long)B * (W / 16) * (H / (32 / L.NT)) * (L.Cout_p / (32 * L.NT));
+    if (wgs_wino >= h->n_cu) return 0;   // k_conv_wino fills the chip
+    const long long w1 = (long long)B * (W / 16) * (H / 8) * (L.Cout_p / 32);
+    const int wb = (w1 >= 2 * h->n_cu && H % 16 == 0) ? 2 : 1;
+    // a workgroup runs Cin / 8 chunks of 16 WB MFMAs per wave back to back: worth it while that loop is short and the launch
+    // still covers at least half of the CUs; deeper / smaller layers stay on the position-split launches
+    if (w1 / wb < h->n_cu / 2 || L.Cin_p > 128) return 0;
+    return wb;
 }
 
 // in: activation view + channel offset/count; out likewise; pool optional
@@ -859,6 +914,16 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         if (out.H != in.H || out.W != in.W) return fail(OG_EINVAL, "conv shape mismatch");
         const double fl = 2.0 * px * 9.0 * L.Cin * L.Cout;
         if (use_wino) {
+            if (const int wb = pick_wino_w(h, L, B, in.H, in.W)) {
+                a.tiles_y = in.H / 8;
+                a.n_spatial = B * a.tiles_x * a.tiles_y;
+                a.wpk = (L.NT == 2) ? L.d_ww1 : L.d_ww;
+                static const char* nmw[2][2] = {{"k_conv_wino_w<1,1>", "k_conv_wino_w<1,2>"}, {"k_conv_wino_w<2,1>", "k_conv_wino_w<2,2>"}};
+                prof_begin(h, L.name, nmw[L.NT - 1][wb - 1], fl);   // <NT of the layer's canonical form, WB>
+                rc = (wb == 1) ? launch_conv_wino_w<1>(ctx, a, L.Cout_p / 32) : launch_conv_wino_w<2>(ctx, a, L.Cout_p / 32);
+                prof_end(h);
+                return rc;
+            }
             a.tiles_y = in.H / (32 / L.NT);
             a.n_spatial = B * a.tiles_x * a.tiles_y;
             a.wpk = L.d_ww;
@@ -1086,7 +1151,8 @@ int enqueue_last_with_head(og_unet* h, int B, float thr, const int32_t* boxes, u
     const int L = h->L;
     const Act& u = h->UA[0];
     // count slots per frame: the fused launch runs on 8x16 tiles (direct kernel) or on 32x16 tiles (k_conv_wino<1>)
-    const bool wino_last = h->wino_chain && h->dec_b[L - 1].d_ww != nullptr && u.H % 32 == 0 && u.W % 16 == 0;
+    const bool wino_last = h->wino_chain && h->dec_b[L - 1].d_ww != nullptr && u.H % 32 == 0 && u.W % 16 == 0 &&
+                           !pick_wino_w(h, h->dec_b[L - 1], B, u.H, u.W);   // k_conv_wino_w counts per 8x16 tile, like the direct kernel
     const int tiles = wino_last ? (u.W / 16) * (u.H / 32) : ((u.W + 15) / 16) * ((u.H + 7) / 8);
     const size_t need = (size_t)B * tiles * 4;
     if (area && need > h->counts_cap) {
@@ -1627,6 +1693,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "wino" && (value == 0 || value == 1)) slot = &h->wino;
     else if (n == "wino_first" && (value == 0 || value == 1)) slot = &h->wino_first;
     else if (n == "wino_ps" && value >= 0 && value <= 4) slot = &h->wino_ps;
+    else if (n == "wino_w" && value >= 0 && value <= 3) slot = &h->wino_w;
     else if (n == "splitk_fused" && (value == 0 || value == 1)) slot = &h->splitk_fused;
     else if (n == "splitk_slots" && value >= 1 && value <= 4) slot = &h->splitk_slots;
     else if (n == "splitk_min_steps" && value >= 1 && value <= 9) slot = &h->splitk_min_steps;

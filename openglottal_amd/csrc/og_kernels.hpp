@@ -1637,6 +1637,271 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_ps(ConvArgs a) {
     }
 }
 
+// WAVE-OWNS-POSITIONS form of k_conv_wino for launches that cannot fill the chip with 64-window tiles (one frame per kernel
+// chain, BASELINE configs[1] / utils.py:235-237): the 16 Winograd positions of a tile are split over the four WAVES of one
+// workgroup instead of over workgroups (k_conv_wino_ps), so the raw accumulators meet in LDS, not in memory -- no 256 KB
+// round trip through the split-K workspace, no arrival counter, no serial reducer.
+//   tile      8 WB x 16 output pixels = WB blocks of 32 windows (4 window rows x 8 window columns) x 32 output channels;
+//             grid = (W / 16, H / (8 WB), frames x Cout / 32): 4 (WB 1) or 2 (WB 2) times k_conv_wino<2>'s workgroups
+//   wave w    row w of the 4x4 position grid: positions 4w .. 4w + 3 = 4 WB accumulators of 32 windows x 32 channels
+//   V         never touches LDS: lane (window, k half) reads the 2 x 4 patch pixels its position row needs (B^T d B per axis is
+//             x[ia] +- x[ib]) from the raw halo, 16 bytes = 4 channels each, and transforms them IN REGISTERS straight into the
+//             MFMA A-fragment layout (the sign of the row op rides in one fma, exactly the rounding of k_conv_wino's add / subtract)
+//   U         a wave's 4 positions of an 8-channel chunk = 4 KB, fetched by that wave alone (LDS-DMA ring, no barrier: only the
+//             issuing wave reads it); the weights are the NT = 1 Winograd image (pack_wino) for every layer
+//   raw halo  32-channel stages, chunk-major image [8-channel chunk][pixel][2 x 16 B] (tools/wino_w_layout_check.py: consistent
+//             and bank-conflict-free), two stages deep; ONE barrier per 32 channels = per 64 WB MFMAs
+//   tail      accumulators -> LDS (lane-linear, 64 KB per block) -> wave e takes window row e of all 16 positions, runs
+//             k_conv_wino's output transform on it and the shared epilogue (conv_epilogue_b on an 8 x 16 tile, one sub-tile per wave)
+// Every per-output sum is k_conv_wino's: channels in groups of 8 in the k order (0,4,1,5,2,6,3,7) of the fragment layout, V and
+// Y = A^T M A by the same adds in the same order -- BIT-IDENTICAL to k_conv_wino<1> and <2> (tests/test_gpu_wino_w.py), so
+// choosing it by micro-batch size is a scheduling choice.
+//   vmcnt     counted, with a uniform issue pattern: per chunk 4 U pieces (UD chunks ahead), per stage RAW_IT raw pieces (one
+//             stage ahead); past the end the pieces are issued with out-of-range offsets (zeros, no traffic) so that the counts
+//             stay compile-time constants.
+template <int WB>
+__global__ __launch_bounds__(256, 1) void k_conv_wino_w(ConvArgs a) {
+    static_assert(WB == 1 || WB == 2, "one or two 32-window blocks per workgroup");
+    constexpr int TH = 8 * WB, RP = 18;
+    constexpr int RAW_PIX = (TH + 2) * RP;               // 180 | 324
+    constexpr int RAW_PIECES = RAW_PIX * 8;              // 16-byte pieces of a 32-channel stage
+    constexpr int RAW_IT = (RAW_PIECES + 255) / 256;     // 6 | 11 LDS-DMA instructions per wave and stage
+    constexpr int RAW_PAD = RAW_IT * 4096;
+    constexpr int GSTRIDE = RAW_PIX * 32;                // bytes between the 8-channel chunks of a stage
+    constexpr int WBSTRIDE = 8 * RP * 32;                // bytes between the window blocks (8 pixel rows)
+    constexpr int UD = (WB == 1) ? 4 : 3;                // U look-ahead in chunks; ring of UD + 1
+    constexpr int US = UD + 1;
+    constexpr int UCH = 16 * 1024;                       // one chunk's weights: [16 positions][32 cout][8 ch]
+    constexpr int UBASE = 2 * RAW_PAD;
+    static_assert(UBASE + US * UCH <= 160 * 1024 && WB * 65536 <= UBASE + US * UCH, "LDS budget / exchange buffer");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+
+    // tile decode: as k_conv_wino (grid.z = frame group x column tile x frame-in-group)
+    const int bz = (int)blockIdx.z;
+    const int gz = a.zdiv << a.zgroup_shift;
+    const int q_ = (gz == 1) ? bz : (int)(((float)bz + 0.5f) * a.zrcp);
+    const int rz = bz - q_ * gz;
+    const int n_tile = rz >> a.zgroup_shift;
+    const int b = (q_ << a.zgroup_shift) + (rz & ((1 << a.zgroup_shift) - 1));
+    if (b >= a.frames) return;
+    const int ty0 = (int)blockIdx.y * TH, tx0 = (int)blockIdx.x * 16;
+    // diagnostic timeline (og_unet_clock_probe only; nullptr on every product path): entry, loop start, loop end, exit
+    unsigned long long* st = nullptr;
+    if (a.stamps != nullptr) {
+        const unsigned wg = ((unsigned)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        st = a.stamps + 4ull * (wg < 1023u ? wg : 1023u);
+        if (tid == 0) st[0] = __builtin_amdgcn_s_memtime();
+    }
+
+    const int n_st = a.n_chunks, n_ck = 4 * a.n_chunks;   // 32-channel stages, 8-channel chunks
+    const og_i32x4 in_rsrc = og_make_rsrc(a.in + (long long)b * a.in_frame_stride + a.in_ch_off,
+                                          (unsigned)(a.in_frame_stride - a.in_ch_off) * 4u);
+    const og_i32x4 w_rsrc = og_make_rsrc(a.wpk + (long long)n_tile * n_ck * (UCH / 4), (unsigned)n_ck * (unsigned)UCH);
+    const unsigned lds0 = og_lds_addr(smem);
+
+    // raw halo pieces of this thread: piece q = it * 256 + tid lands at LDS byte 16 q of the stage's buffer and is
+    // (chunk g, pixel P = hy * RP + (hx & 1) * 9 + (hx >> 1), half hp) holding channels 8 g + 4 (hp ^ (hy >> 2 & 1)) ..
+    unsigned hoff[RAW_IT];
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) {
+        const int q = it * 256 + tid;
+        const int g = q / (2 * RAW_PIX), rem = q - g * (2 * RAW_PIX);
+        const int P = rem >> 1, hp = rem & 1;
+        const int hy = P / RP, r18 = P - hy * RP;
+        const int hx = (r18 >= 9) ? 2 * (r18 - 9) + 1 : 2 * r18;
+        const int lg = hp ^ ((hy >> 2) & 1);
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        const bool inb = q < RAW_PIECES && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        hoff[it] = inb ? (unsigned)((gy * a.W + gx) * a.in_pix_stride * 4 + g * 32 + lg * 16) : OG_OOB;
+    }
+    auto issue_raw = [&](int s) {   // stage s -> raw[s & 1]; past the last stage: zero records (zeros, no traffic), same count
+        og_i32x4 rs = in_rsrc;
+        rs.z = (s < n_st) ? in_rsrc.z : 0;
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((s & 1) * RAW_PAD) + wave * 1024);
+#pragma unroll
+        for (int it = 0; it < RAW_IT; ++it) glds16b(hoff[it], rs, (unsigned)s * 128u, base + it * 4096);
+    };
+    auto issue_u = [&](int c) {   // positions 4 wave .. + 3 of chunk c -> U[c % US]; past the last chunk: zero records, as above
+        og_i32x4 ws = w_rsrc;
+        ws.z = (c < n_ck) ? w_rsrc.z : 0;
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + UBASE + (unsigned)((c % US) * UCH) + wave * 4096);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) glds16b((unsigned)lane * 16u, ws, (unsigned)((c * 16 + 4 * wave + cc) * 1024), base + cc * 1024);
+    };
+    issue_raw(0);
+#pragma unroll
+    for (int c = 0; c <= UD; ++c) issue_u(c);
+    issue_raw(1);
+
+    // position row of this wave: B^T row i = x[ra] (+ if i == 1, else -) x[rb]
+    const int ra = (wave == 0) ? 0 : (wave == 2) ? 2 : 1;
+    const int rb = (wave == 0) ? 2 : (wave == 1) ? 2 : (wave == 2) ? 1 : 3;
+    const float rsgn = (wave == 1) ? 1.0f : -1.0f;
+    // MFMA row li = window (row wr, column wc) of a block; patch pixel (r, pc) of it at P = (2 wr + r) RP + (pc & 1) 9 + wc + (pc >> 1)
+    const int wr = li & 3, wc = 2 * (li >> 3) + ((li >> 2) & 1);
+    unsigned rbase[2][4];
+#pragma unroll
+    for (int rsel = 0; rsel < 2; ++rsel) {
+        const int hy = 2 * wr + (rsel ? rb : ra);
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            rbase[rsel][pc] = lds0 + (unsigned)((hy * RP + (pc & 1) * 9 + wc + (pc >> 1)) * 32 + ((lh ^ ((hy >> 2) & 1)) << 4));
+            asm volatile("" : "+v"(rbase[rsel][pc]));
+        }
+    }
+    unsigned ubase = lds0 + UBASE + (unsigned)(wave * 4096 + li * 32 + ((lh ^ ((li >> 3) & 1)) << 4));
+    asm volatile("" : "+v"(ubase));
+    const int ecol = n_tile * 32 + li;
+    const float esc = a.scale[ecol], esh = a.shift[ecol];
+
+    f32x16 acc[WB][4];
+#pragma unroll
+    for (int wb = 0; wb < WB; ++wb)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[wb][cc][r] = 0.f;
+            asm volatile("" : "+a"(acc[wb][cc]));   // zeroed here, under the latency of the first DMAs (as k_conv_wino)
+        }
+
+    f32x4 tv[2][WB][4], bv[2][4], rd[WB][2][4];
+    auto fma4 = [](float sgn, f32x4 b_, f32x4 a_) {
+        return f32x4{fmaf(sgn, b_.x, a_.x), fmaf(sgn, b_.y, a_.y), fmaf(sgn, b_.z, a_.z), fmaf(sgn, b_.w, a_.w)};
+    };
+    auto read_chunk = [&](int s, int j, int c, int to) {   // raw patch pixels and weight fragments of chunk c = 4 s + j
+        const unsigned ro = (unsigned)((s & 1) * RAW_PAD + j * GSTRIDE);
+#pragma unroll
+        for (int wb = 0; wb < WB; ++wb)
+#pragma unroll
+            for (int rsel = 0; rsel < 2; ++rsel)
+#pragma unroll
+                for (int pc = 0; pc < 4; ++pc) rd[wb][rsel][pc] = og_lds_read16(rbase[rsel][pc] + ro + (unsigned)(wb * WBSTRIDE));
+        const unsigned uo = (unsigned)((c % US) * UCH);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) bv[to][cc] = og_lds_read16(ubase + uo + (unsigned)(cc * 1024));
+    };
+    // quad-op n of the transform of block wb: 0-3 row op of patch column n (t = x[ra] +- x[rb]), 4-7 column op -> position 4 w + (n - 4)
+    f32x4 t[WB][4];
+    auto xf = [&](int wb, int n, int to) {
+        if (n < 4) t[wb][n] = fma4(rsgn, rd[wb][1][n], rd[wb][0][n]);
+        else if (n == 4) tv[to][wb][0] = t[wb][0] - t[wb][2];
+        else if (n == 5) tv[to][wb][1] = t[wb][1] + t[wb][2];
+        else if (n == 6) tv[to][wb][2] = t[wb][2] - t[wb][1];
+        else tv[to][wb][3] = t[wb][1] - t[wb][3];
+    };
+
+    // workgroup barrier WITHOUT a fence: __syncthreads() would make hipcc wait vmcnt(0) for the loads it tracks (scale / shift), i.e.
+    // for every LDS-DMA queued behind them; hipcc's own LDS reads are waited for here, the DMA by the counted vmcnt in front
+    auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * UD + RAW_IT) : "memory");   // raw(0) and U(0) landed; U(1..UD), raw(1) in flight
+    barrier();
+    read_chunk(0, 0, 0, 0);
+#pragma unroll
+    for (int wb = 0; wb < WB; ++wb)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) xf(wb, n, 0);
+    if (st != nullptr && tid == 0) st[1] = __builtin_amdgcn_s_memtime();
+
+    // 16 WB MFMAs of a chunk (fragments in tv / bv[cur]); with `more`, one quad-op (4 vector-ALU instructions) of the next
+    // chunk's transform behind every second one
+    auto mfma_chunk = [&](int cur, bool more) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int wb = 0; wb < WB; ++wb)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int n = (e * WB + wb) * 4 + cc;   // 0 .. 16 WB - 1
+                    const float av = tv[cur][wb][cc][e], bw = bv[cur][cc][e];
+                    acc[wb][cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw, acc[wb][cc], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more && (n & 1)) xf((n >> 1) >> 3, (n >> 1) & 7, cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+    };
+    for (int s = 0; s < n_st; ++s) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {   // chunks 4 s + j, j < 3: the next chunk is in the same stage
+            const int c = 4 * s + j;
+            // U(c + 1): younger than it are U(c + 2 .. c + UD) and the raw stage issued in the last UD chunks, if any
+            if (UD == 4 || j != 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (UD - 1) + RAW_IT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (UD - 1)) : "memory");
+            issue_u(c + 1 + UD);
+            read_chunk(s, j + 1, c + 1, (j & 1) ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_chunk(j & 1, true);
+        }
+        if (s + 1 < n_st) {
+            // chunk 4 s + 3: the next chunk opens stage s + 1 -- its raw halo has landed for every wave behind this barrier, and
+            // every read of stage s (taken a chunk ago) has returned, so its buffer takes stage s + 2
+            if (s == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            barrier();
+            issue_raw(s + 2);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (UD - 1) + RAW_IT) : "memory");
+            issue_u(4 * s + 4 + UD);
+            read_chunk(s + 1, 0, 4 * s + 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_chunk(1, true);
+        } else {
+            mfma_chunk(1, false);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the out-of-range tail pieces still write (zeros) into the rings
+    barrier();
+    if (st != nullptr && tid == 0) st[2] = __builtin_amdgcn_s_memtime();
+
+    // ---- exchange: every wave's 4 positions -> LDS, lane-linear; wave e takes window row e (accumulator registers 4 q + e) of all
+    //      16 positions = the register set k_conv_wino's output transform combines into sub-tile e of the direct accumulator layout ----
+#pragma unroll
+    for (int wb = 0; wb < WB; ++wb)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 v = {acc[wb][cc][e], acc[wb][cc][4 + e], acc[wb][cc][8 + e], acc[wb][cc][12 + e]};
+                *(OG_LDS_AS f32x4*)(unsigned long long)(lds0 + (unsigned)((((wb * 4 + e) * 16 + cc) * 64) * 16) + (unsigned)(wave * 4 * 64 * 16 + lane * 16)) = v;
+            }
+    __syncthreads();
+    f32x16 o[WB];
+#pragma unroll
+    for (int wb = 0; wb < WB; ++wb) {
+        f32x4 m[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) m[p] = og_lds_read16(lds0 + (unsigned)(((wb * 4) * 16 + p) * 64 * 16) + (unsigned)(wave * 16 * 64 * 16 + lane * 16));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // Y = A^T M A exactly as k_conv_wino writes it (its register r = 4 q + wave)
+            float tm[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tm[0][j] = m[0 + j][q] + m[4 + j][q] + m[8 + j][q];
+                tm[1][j] = m[4 + j][q] - m[8 + j][q] - m[12 + j][q];
+            }
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                o[wb][4 * q + 2 * y + 0] = tm[y][0] + tm[y][1] + tm[y][2];
+                o[wb][4 * q + 2 * y + 1] = tm[y][1] - tm[y][2] - tm[y][3];
+            }
+        }
+    }
+    __syncthreads();   // the exchange buffer is dead: the epilogue's per-wave scratch overlays it
+    unsigned char* const scr = smem + wave * 5120;
+#pragma unroll
+    for (int wb = 0; wb < WB; ++wb) {
+        if (a.act == 1) conv_epilogue_b<1, 0, 8, 1, false>(a, &o[wb], n_tile, b, ty0 + 8 * wb, tx0, wave, 0, li, lh, esc, esh, scr);
+        else conv_epilogue_b<1, 0, 8, 0, false>(a, &o[wb], n_tile, b, ty0 + 8 * wb, tx0, wave, 0, li, lh, esc, esh, scr);
+    }
+    if (st != nullptr && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st[3] = __builtin_amdgcn_s_memtime();
+    }
+}
+
 // Split-precision twin of k_conv_mfma_o (MODE 0: 3x3 conv, MODE 1: 2x2 stride-2 transposed conv): same tiles, halo /
 // weight staging, LDS images, swizzles and fragment addressing; the operands are f16 hi/lo pairs in the H layout and each
 // (chunk, tap) costs 6 x v_mfma_f32_32x32x16_f16 per 32-row sub-tile instead of 16 x v_mfma_f32_32x32x2_f32.  No split-K.

@@ -128,7 +128,7 @@ def test_same_kernels_at_every_micro_batch_size(base):
 
     def form(kernel):
         assert "splitK" not in kernel, kernel
-        if kernel.startswith("k_conv_wino_ps<"):     # position-split launch of the same form (same sums, more workgroups)
+        if kernel.startswith(("k_conv_wino_ps<", "k_conv_wino_w<")):     # position-split / wave-split launch of the same form (same sums)
             return "k_conv_wino<" + kernel.split("<")[1].split(",")[0] + ">"
         return kernel if kernel.startswith(("k_conv_wino", "k_conv_first")) else "direct:" + kernel.split("<")[1].split(",")[1]   # MODE
 
