@@ -106,6 +106,7 @@ struct og_unet {
     };
     std::vector<ProfEntry>* prof = nullptr;
     unsigned long long* d_stamps = nullptr;  // [64 launches][1024 workgroups][4], allocated by og_unet_clock_probe
+    bool probing = false;                    // set for the duration of og_unet_clock_probe only: no other call makes a kernel write stamps
     int chunk = 32;
     int use_graphs = 1;
     int conv_impl = 2;   // 0 k_conv_mfma | 1 k_conv_mfma_p (persistent, pipelined) | 2 auto: k_conv_mfma_o (3 WG/CU, single halo
@@ -904,7 +905,7 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         }
     }
     a.stamps = nullptr;
-    if (h->prof && h->d_stamps) {  // diagnostic clock stamps, profile runs only
+    if (h->probing && h->prof && h->d_stamps) {  // diagnostic clock stamps: og_unet_clock_probe only
         a.stamps = h->d_stamps + 4 * 1024 * h->prof->size();
     }
     const double px = (double)B * in.H * in.W;
@@ -2228,9 +2229,12 @@ int og_unet_clock_probe(og_unet* h, const uint8_t* gray_dev, int B, int H, int W
     HIPCHK(hipMemsetAsync(h->d_stamps, 0, nst * 8, h->stream));
     std::vector<og_unet::ProfEntry> tr;
     h->prof = &tr;
+    h->probing = true;
+    pick_chain_form(h, B, H, W);   // the chain the product runs (og_unet_profile's), not whatever form the last call left behind
     rc = enqueue_first(h, KIND_U8, gray_dev, B, H, W);
     if (!rc) rc = enqueue_body(h, B);
     h->prof = nullptr;
+    h->probing = false;
     hipError_t e = hipStreamSynchronize(h->stream);
     for (auto& t : tr) {
         (void)hipEventDestroy(t.e0);

@@ -1707,17 +1707,21 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w(ConvArgs a) {
     // raw halo pieces of this thread: piece q = it * 256 + tid lands at LDS byte 16 q of the stage's buffer and is
     // (chunk g, pixel P = hy * RP + (hx & 1) * 9 + (hx >> 1), half hp) holding channels 8 g + 4 (hp ^ (hy >> 2 & 1)) ..
     unsigned hoff[RAW_IT];
+    {   // q walks in steps of 256 pieces = 128 pixels = 7 image rows + 2 pixels: one division for the first piece, then adds
+        int g = 0, hy = (tid >> 1) / RP, r18 = (tid >> 1) - hy * RP;
+        const int hp = tid & 1;
 #pragma unroll
-    for (int it = 0; it < RAW_IT; ++it) {
-        const int q = it * 256 + tid;
-        const int g = q / (2 * RAW_PIX), rem = q - g * (2 * RAW_PIX);
-        const int P = rem >> 1, hp = rem & 1;
-        const int hy = P / RP, r18 = P - hy * RP;
-        const int hx = (r18 >= 9) ? 2 * (r18 - 9) + 1 : 2 * r18;
-        const int lg = hp ^ ((hy >> 2) & 1);
-        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-        const bool inb = q < RAW_PIECES && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        hoff[it] = inb ? (unsigned)((gy * a.W + gx) * a.in_pix_stride * 4 + g * 32 + lg * 16) : OG_OOB;
+        for (int it = 0; it < RAW_IT; ++it) {
+            const int hx = (r18 >= 9) ? 2 * (r18 - 9) + 1 : 2 * r18;
+            const int lg = hp ^ ((hy >> 2) & 1);
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            const bool inb = it * 256 + tid < RAW_PIECES && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            hoff[it] = inb ? (unsigned)((gy * a.W + gx) * a.in_pix_stride * 4 + g * 32 + lg * 16) : OG_OOB;
+            r18 += 128 % RP;
+            hy += 128 / RP;
+            if (r18 >= RP) { r18 -= RP; hy += 1; }
+            if (hy >= TH + 2) { hy -= TH + 2; g += 1; }
+        }
     }
     auto issue_raw = [&](int s) {   // stage s -> raw[s & 1]; past the last stage: zero records (zeros, no traffic), same count
         og_i32x4 rs = in_rsrc;
@@ -1773,17 +1777,12 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w(ConvArgs a) {
     auto fma4 = [](float sgn, f32x4 b_, f32x4 a_) {
         return f32x4{fmaf(sgn, b_.x, a_.x), fmaf(sgn, b_.y, a_.y), fmaf(sgn, b_.z, a_.z), fmaf(sgn, b_.w, a_.w)};
     };
-    auto read_chunk = [&](int s, int j, int c, int to) {   // raw patch pixels and weight fragments of chunk c = 4 s + j
-        const unsigned ro = (unsigned)((s & 1) * RAW_PAD + j * GSTRIDE);
+    constexpr int NR = 8 * WB;   // raw patch reads per chunk: index r = (block, row select, patch column)
+    unsigned rcur[2][4];   // rbase + the ring buffer of the stage being read (8 adds per stage, not one per read)
 #pragma unroll
-        for (int wb = 0; wb < WB; ++wb)
-#pragma unroll
-            for (int rsel = 0; rsel < 2; ++rsel)
-#pragma unroll
-                for (int pc = 0; pc < 4; ++pc) rd[wb][rsel][pc] = og_lds_read16(rbase[rsel][pc] + ro + (unsigned)(wb * WBSTRIDE));
-        const unsigned uo = (unsigned)((c % US) * UCH);
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) bv[to][cc] = og_lds_read16(ubase + uo + (unsigned)(cc * 1024));
+    for (int i = 0; i < 8; ++i) rcur[i >> 2][i & 3] = rbase[i >> 2][i & 3];
+    auto read_raw = [&](int r, int j) {   // chunk j of the stage: a compile-time offset of the read
+        rd[r >> 3][(r >> 2) & 1][r & 3] = og_lds_read16(rcur[(r >> 2) & 1][r & 3] + (unsigned)(j * GSTRIDE + (r >> 3) * WBSTRIDE));
     };
     // quad-op n of the transform of block wb: 0-3 row op of patch column n (t = x[ra] +- x[rb]), 4-7 column op -> position 4 w + (n - 4)
     f32x4 t[WB][4];
@@ -1800,58 +1799,86 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w(ConvArgs a) {
     auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * UD + RAW_IT) : "memory");   // raw(0) and U(0) landed; U(1..UD), raw(1) in flight
     barrier();
-    read_chunk(0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) read_raw(r, 0);
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) bv[0][cc] = og_lds_read16(ubase + (unsigned)(cc * 1024));
 #pragma unroll
     for (int wb = 0; wb < WB; ++wb)
 #pragma unroll
         for (int n = 0; n < 8; ++n) xf(wb, n, 0);
     if (st != nullptr && tid == 0) st[1] = __builtin_amdgcn_s_memtime();
 
-    // 16 WB MFMAs of a chunk (fragments in tv / bv[cur]); with `more`, one quad-op (4 vector-ALU instructions) of the next
-    // chunk's transform behind every second one
-    auto mfma_chunk = [&](int cur, bool more) {
+    // One chunk: 16 WB MFMAs on the fragments tv / bv[cur].  One wave per SIMD: nothing but this wave's own instruction stream can
+    // fill the matrix pipe's shadow, so the side work of the NEXT chunk (c_rd = 4 s_rd + j_rd) is cut into micro-ops with a fixed
+    // slot behind the MFMAs (as k_conv_wino does): slot 0 the waits (+ the stage barrier), then 2 LDS reads per slot, the 4 U pieces
+    // of chunk c_rd + UD one per slot, the transform one quad-op per slot, and on a stage boundary (MODE 2) the raw pieces of stage
+    // s_rd + 1 one per slot.  MODE 0: last chunk, MFMAs only.
+    constexpr int S_DU = NR / 2 + 2, S_X = NR / 2 + 3, S_DR = NR / 2 + 6;
+    static_assert(S_X + 8 * WB <= 16 * WB && S_DR + RAW_IT <= 16 * WB, "side work of a chunk must fit its MFMA slots");
+    auto chunk = [&](int cur, int mode, int s_rd, int j_rd, int c_rd) {
+        const unsigned ucur = ubase + (unsigned)((c_rd % US) * UCH);
+        const int cu = c_rd + UD;
+        og_i32x4 ws = w_rsrc, rs = in_rsrc;
+        ws.z = (cu < n_ck) ? w_rsrc.z : 0;            // past the end: zero records -> zeros, no traffic, same vmcnt count
+        rs.z = (s_rd + 1 < n_st) ? in_rsrc.z : 0;
+        const unsigned ub = __builtin_amdgcn_readfirstlane(lds0 + UBASE + (unsigned)((cu % US) * UCH) + wave * 4096);
+        const unsigned us = (unsigned)((cu * 16 + 4 * wave) * 1024);
+        const unsigned rbs = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(((s_rd + 1) & 1) * RAW_PAD) + wave * 1024);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int wb = 0; wb < WB; ++wb)
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
-                    const int n = (e * WB + wb) * 4 + cc;   // 0 .. 16 WB - 1
+                    const int n = (e * WB + wb) * 4 + cc;   // slot 0 .. 16 WB - 1
                     const float av = tv[cur][wb][cc][e], bw = bv[cur][cc][e];
                     acc[wb][cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw, acc[wb][cc], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (more && (n & 1)) xf((n >> 1) >> 3, (n >> 1) & 7, cur ^ 1);
+                    if (mode != 0) {
+                        if (n == 0) {
+                            if (mode == 2) {
+                                // the next chunk opens stage s_rd: its raw halo (issued 4 chunks = 12 younger U pieces ago) has landed
+                                // for every wave behind this barrier, and every read of stage s_rd - 1 (taken a chunk ago) has
+                                // returned, so that buffer takes stage s_rd + 1 below
+                                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                                barrier();
+                            }
+                            // U(c_rd): younger than it are U(c_rd + 1 .. c_rd + UD - 1) and the raw stage issued in the UD chunks
+                            // before this one, if any
+                            if (UD == 4 || mode != 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (UD - 1) + RAW_IT) : "memory");
+                            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (UD - 1)) : "memory");
+                            if (mode == 2) {
+                                const unsigned ring = (unsigned)((s_rd & 1) * RAW_PAD);
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) rcur[i >> 2][i & 3] = rbase[i >> 2][i & 3] + ring;
+                            }
+                        }
+                        if (n < NR / 2) {
+                            read_raw(2 * n, j_rd);
+                            read_raw(2 * n + 1, j_rd);
+                        } else if (n < NR / 2 + 2) {
+                            const int c0 = 2 * (n - NR / 2);
+                            bv[cur ^ 1][c0] = og_lds_read16(ucur + (unsigned)(c0 * 1024));
+                            bv[cur ^ 1][c0 + 1] = og_lds_read16(ucur + (unsigned)((c0 + 1) * 1024));
+                        }
+                        if (n >= S_DU && n < S_DU + 4) glds16b((unsigned)lane * 16u, ws, us + (unsigned)((n - S_DU) * 1024), ub + (n - S_DU) * 1024);
+                        if (n >= S_X && n < S_X + 8 * WB) xf((n - S_X) >> 3, (n - S_X) & 7, cur ^ 1);
+                        if (mode == 2 && n >= S_DR && n < S_DR + RAW_IT) glds16b(hoff[n - S_DR], rs, (unsigned)(s_rd + 1) * 128u, rbs + (n - S_DR) * 4096);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
     };
-    for (int s = 0; s < n_st; ++s) {
+    // (the last stage is peeled: a branch inside the loop made hipcc keep two copies of the accumulators and move all 64 WB
+    //  registers there and back once per stage)
+    for (int s = 0; s + 1 < n_st; ++s) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {   // chunks 4 s + j, j < 3: the next chunk is in the same stage
-            const int c = 4 * s + j;
-            // U(c + 1): younger than it are U(c + 2 .. c + UD) and the raw stage issued in the last UD chunks, if any
-            if (UD == 4 || j != 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (UD - 1) + RAW_IT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (UD - 1)) : "memory");
-            issue_u(c + 1 + UD);
-            read_chunk(s, j + 1, c + 1, (j & 1) ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(j & 1, true);
-        }
-        if (s + 1 < n_st) {
-            // chunk 4 s + 3: the next chunk opens stage s + 1 -- its raw halo has landed for every wave behind this barrier, and
-            // every read of stage s (taken a chunk ago) has returned, so its buffer takes stage s + 2
-            if (s == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            barrier();
-            issue_raw(s + 2);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (UD - 1) + RAW_IT) : "memory");
-            issue_u(4 * s + 4 + UD);
-            read_chunk(s + 1, 0, 4 * s + 4, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(1, true);
-        } else {
-            mfma_chunk(1, false);
-        }
+        for (int j = 0; j < 3; ++j) chunk(j & 1, 1, s, j + 1, 4 * s + j + 1);   // chunks 4 s + j, j < 3: the next chunk is in the same stage
+        chunk(1, 2, s + 1, 0, 4 * s + 4);                                        // chunk 4 s + 3 before another stage
     }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) chunk(j & 1, 1, n_st - 1, j + 1, 4 * (n_st - 1) + j + 1);
+    chunk(1, 0, 0, 0, 0);                                                        // the last chunk: MFMAs only
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the out-of-range tail pieces still write (zeros) into the rings
     barrier();
     if (st != nullptr && tid == 0) st[2] = __builtin_amdgcn_s_memtime();

@@ -1,4 +1,4 @@
-"""In-kernel timeline of the position-split Winograd launches of a one-frame chain: per launch, medians over the workgroups of
+"""In-kernel timeline of the position-split (k_conv_wino_ps) and wave-split (k_conv_wino_w) Winograd launches of a one-frame chain: per launch, medians over the workgroups of
 entry -> loop start, loop, loop end -> exit (non-reducing workgroups) / -> exit of the reducing workgroup, in microseconds of
 shader clock (s_memtime / measured MHz)."""
 import ctypes as C, os, sys
@@ -15,8 +15,12 @@ prof = m.profile(fr, B, 256, 256, reps=2)
 m.clock_probe(fr, B, 256, 256)
 mhz = 2400.0
 buf = np.zeros((1024, 4), np.uint64)
+for kv in sys.argv[2:]:
+    k_, v_ = kv.split("="); m.set_option(k_, int(v_))
+prof = m.profile(fr, B, 256, 256, reps=2)
+m.clock_probe(fr, B, 256, 256)
 for i, p in enumerate(prof[:-0 or None]):
-    if not p["kernel"].startswith("k_conv_wino_ps"):
+    if not p["kernel"].startswith(("k_conv_wino_ps", "k_conv_wino_w")):
         continue
     check(lib().og_unet_clock_probe_raw(m._h, i, ptr(buf)), "raw")
     v = buf[buf[:, 0] > 0]
