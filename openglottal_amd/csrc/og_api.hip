@@ -122,7 +122,9 @@ struct og_unet {
     int wino_ps = 1;     // under-filled Winograd launches spread a tile's 16 positions over several workgroups (k_conv_wino_ps: bit-identical);
                          // 0 off, 1 auto, 2 / 3 / 4 force PN = 4 / 2 / 1 on every launch that qualifies
     int wino_w = 1;      // under-filled Winograd launches on k_conv_wino_w (the 16 positions over the four waves of a workgroup, finer
-                         // tiles: bit-identical); 0 off, 1 auto, 2 / 3 force WB = 1 / 2 on every Winograd layer (tests, A/B)
+                         // tiles) / k_conv_wino_wp (its position rows on four workgroups): bit-identical; 0 off, 1 auto,
+                         // 2 / 3 force k_conv_wino_w<1> / <2>, 4 forces k_conv_wino_wp on every Winograd layer (tests, A/B)
+    int active_lanes = 1; // lanes of the call in progress (set by the entry points on every lane): scheduling hint for pick_wino_w
     int wino_first = 1;  // Winograd chains: first layer unfused so that the second conv takes k_conv_wino<1>
     bool wino_chain = false;   // (pick_chain_form) wino && precision == 0 && conv_impl == 2
     int splitk_nt1 = 1;  // split 3x3 launches on 32-column tiles (twice the workgroups, half the MFMAs per K part)
@@ -152,6 +154,7 @@ struct og_unet {
         int32_t* area = nullptr;
     } fuse;
     int convt_occ = 1;   // with conv_impl >= 2: run the transposed convs on the occupancy variant too
+    int convt_w = 1;     // under-filled transposed-conv launches on k_convt_w (wave-sized tiles, operands straight to registers: bit-identical)
     int tile_h = 0;      // 0 auto (16x16 tiles for 64-channel-tile layers at <= 64x64 pixels, else 8x16) | 8 | 16
     int splitk = 0;      // OPT-IN (non-canonical): split K over workgroups on launches that would fill < 1/div of the chip.  It changes the
                          // summation order, so a frame's logits then depend on how many frames share its launch; off by default
@@ -363,6 +366,7 @@ int build_convT(og_unet* h, ConvLayer& L, const std::string& p, int Cin, int Cou
     }
     int rc;
     if ((rc = upload(pk, &L.d_w))) return rc;
+    if ((rc = upload(pack_gemm_b(4 * Cop, L.Cin_p, 1, 1, at), &L.d_w1))) return rc;   // 32-column tiles (k_convt_w)
     if ((rc = upload(pack_gemm_b_h(4 * Cop, L.Cin_p, 1, L.NT, at), &L.d_w_h))) return rc;
     if ((rc = upload(sc, &L.d_scale))) return rc;
     if ((rc = upload(sh, &L.d_shift))) return rc;
@@ -631,6 +635,24 @@ int launch_conv_wino_w(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     return OG_OK;
 }
 
+constexpr int kWinoWpLds = 3 * 6 * 4096 + 9 * 4096;
+
+// k_conv_wino_wp: k_conv_wino_w<1>'s tiles, a tile's four position rows on four workgroups (grid.z x 4); needs the split-K workspace
+// (64 KB per tile) and the arrival counters
+int launch_conv_wino_wp(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
+    ConvArgs a = a_in;   // (a.stamps: per-workgroup timeline of diagnostic runs, 4 x u64 for up to 1024 workgroups)
+    a.ksplit = 1;
+    const int frames = a.n_spatial / (a.tiles_x * a.tiles_y);
+    a.zdiv = n_ntiles;
+    a.frames = frames;
+    a.zgroup_shift = 0;
+    a.zrcp = 1.0f / (float)a.zdiv;
+    if ((long long)frames * a.zdiv * 4 > 65535) return fail(OG_EINVAL, "k_conv_wino_wp: grid.z");
+    hipLaunchKernelGGL(k_conv_wino_wp, dim3(a.tiles_x, a.tiles_y, frames * a.zdiv * 4), dim3(256), kWinoWpLds, c.stream, a);
+    HIPCHK(hipGetLastError());
+    return OG_OK;
+}
+
 template <int NT, int MODE, int TH, int OCC, bool SQ = false>
 int launch_conv_h(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {   // split-precision twin of launch_conv_o (no split-K)
     constexpr int lds = conv_o_lds<NT, MODE, TH>();
@@ -709,6 +731,7 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_lds<1>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_w<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_w_lds<1>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_w<2>, hipFuncAttributeMaxDynamicSharedMemorySize, wino_w_lds<2>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_wp, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoWpLds));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_ps<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (wino_ps_lds<2, 1>())));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_ps<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (wino_ps_lds<2, 2>())));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_wino_ps<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (wino_ps_lds<2, 4>())));
@@ -738,19 +761,24 @@ int init_kernel_attrs() {  // must not run inside a stream capture
 }
 
 // Which Winograd kernel runs a 3x3 layer that takes the Winograd form (decided by the caller from options and (H, W) alone):
-// 0 = k_conv_wino / k_conv_wino_ps, 1 / 2 = k_conv_wino_w<WB>.  All of them compute the same bits, so B may enter here.
+// 0 = k_conv_wino / k_conv_wino_ps, 1 / 2 = k_conv_wino_w<WB>, 4 = k_conv_wino_wp.  All of them compute the same bits, so B may
+// enter here.
 int pick_wino_w(const og_unet* h, const ConvLayer& L, int B, int H, int W) {
     if (!h->wino_w || (L.NT == 2 && L.d_ww1 == nullptr) || H % 8 || W % 16) return 0;
+    const long long w1 = (long long)B * (W / 16) * (H / 8) * (L.Cout_p / 32);   // 8 x 16-pixel x 32-channel tiles
+    const bool wp_ok = h->d_partial != nullptr && h->d_tile_counter != nullptr && w1 <= 1024 && w1 * 65536 <= (long long)kPartialBytes;
     if (h->wino_w == 2) return 1;
     if (h->wino_w == 3) return (H % 16 == 0) ? 2 : 1;
+    if (h->wino_w == 4) return wp_ok ? 4 : 1;
     const long long wgs_wino = (long long)B * (W / 16) * (H / (32 / L.NT)) * (L.Cout_p / (32 * L.NT));
-    if (wgs_wino >= h->n_cu) return 0;   // k_conv_wino fills the chip
-    const long long w1 = (long long)B * (W / 16) * (H / 8) * (L.Cout_p / 32);
-    const int wb = (w1 >= 2 * h->n_cu && H % 16 == 0) ? 2 : 1;
-    // a workgroup runs Cin / 8 chunks of 16 WB MFMAs per wave back to back: worth it while that loop is short and the launch
-    // still covers at least half of the CUs; deeper / smaller layers stay on the position-split launches
-    if (w1 / wb < h->n_cu / 2 || L.Cin_p > 128) return 0;
-    return wb;
+    if (wgs_wino * 2 > h->n_cu) return 0;   // k_conv_wino covers more than half of the chip: its larger tiles stream less
+    // One chain at a time (one lane): latency counts -- a k_conv_wino_w workgroup runs Cin / 8 chunks of 16 MFMAs per wave back to
+    // back, so layers with few tiles and hundreds of channels also split the position rows (measured at one frame: 64 tiles and
+    // fewer; 128 tiles are faster unsplit up to 256 channels).  Several lanes in flight: occupancy counts -- the unsplit kernel
+    // stages and transforms every halo once and exchanges nothing through memory (half the CU-time per layer), and the other
+    // lanes' launches fill the CUs it leaves idle (3 lanes, one frame per chain: 5.0 k frames/s against 4.4 k).
+    if (h->active_lanes <= 1 && w1 * 4 <= h->n_cu && wp_ok) return 4;
+    return (w1 >= 2 * h->n_cu && H % 16 == 0) ? 2 : 1;
 }
 
 // in: activation view + channel offset/count; out likewise; pool optional
@@ -919,9 +947,16 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
                 a.tiles_y = in.H / 8;
                 a.n_spatial = B * a.tiles_x * a.tiles_y;
                 a.wpk = (L.NT == 2) ? L.d_ww1 : L.d_ww;
-                static const char* nmw[2][2] = {{"k_conv_wino_w<1,1>", "k_conv_wino_w<1,2>"}, {"k_conv_wino_w<2,1>", "k_conv_wino_w<2,2>"}};
-                prof_begin(h, L.name, nmw[L.NT - 1][wb - 1], fl);   // <NT of the layer's canonical form, WB>
-                rc = (wb == 1) ? launch_conv_wino_w<1>(ctx, a, L.Cout_p / 32) : launch_conv_wino_w<2>(ctx, a, L.Cout_p / 32);
+                static const char* nmw[2][3] = {{"k_conv_wino_w<1,1>", "k_conv_wino_w<1,2>", "k_conv_wino_wp<1>"},
+                                                {"k_conv_wino_w<2,1>", "k_conv_wino_w<2,2>", "k_conv_wino_wp<2>"}};
+                prof_begin(h, L.name, nmw[L.NT - 1][wb == 4 ? 2 : wb - 1], fl);   // <NT of the layer's canonical form[, WB]>
+                if (wb == 4) {
+                    a.partial = h->d_partial;
+                    a.tile_counter = h->d_tile_counter;
+                    rc = launch_conv_wino_wp(ctx, a, L.Cout_p / 32);
+                } else {
+                    rc = (wb == 1) ? launch_conv_wino_w<1>(ctx, a, L.Cout_p / 32) : launch_conv_wino_w<2>(ctx, a, L.Cout_p / 32);
+                }
                 prof_end(h);
                 return rc;
             }
@@ -1015,6 +1050,19 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
     }
     if (out.H != 2 * in.H || out.W != 2 * in.W) return fail(OG_EINVAL, "convT shape mismatch");
     const double flt = 2.0 * px * 4.0 * L.Cin * L.Cout;
+    // a launch that leaves most of the chip idle (one frame per chain): the same sums on 32-pixel x 32-column wave tiles -- a
+    // scheduling choice among bit-identical kernels, so B may enter
+    if (h->conv_impl == 2 && a.ksplit == 1 && h->convt_w && L.d_w1 != nullptr && (long long)B * a.tiles_x * ((in.H + 7) / 8) * (4 * L.Cout_p / 64) * 2 <= h->n_cu) {
+        a.wpk = L.d_w1;
+        a.zdiv = L.Cout_p / 32;   // column tiles of 32 / 4 per workgroup
+        a.frames = B;
+        if ((long long)B * a.zdiv > 65535) return fail(OG_EINVAL, "k_convt_w: grid.z");
+        prof_begin(h, L.name, "k_convt_w<1,1,8>", flt);
+        hipLaunchKernelGGL(k_convt_w, dim3((in.W + 15) / 16, (in.H + 1) / 2, B * a.zdiv), dim3(256), 0, h->stream, a);
+        prof_end(h);
+        HIPCHK(hipGetLastError());
+        return OG_OK;
+    }
     if (impl == 0) {
         prof_begin(h, L.name, "k_conv_mfma<2,1,8>", flt);
         rc = launch_conv_t<2, 1, TH>(h, a, 4 * L.Cout_p / 64);
@@ -1226,7 +1274,7 @@ int run_chunk(og_unet* h, int kind, const void* in, int B, int H, int W, float t
         key.B = B;
         key.H = H;
         key.W = W;
-        key.flags = (fuse ? 1 : 0) | (ff ? 2 : 0) | (h->precision ? 4 : 0) | (h->wino_chain ? 8 : 0);
+        key.flags = (fuse ? 1 : 0) | (ff ? 2 : 0) | (h->precision ? 4 : 0) | (h->wino_chain ? 8 : 0) | (h->active_lanes > 1 ? 16 : 0);
         key.capB = h->capB;
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
@@ -1694,7 +1742,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "wino" && (value == 0 || value == 1)) slot = &h->wino;
     else if (n == "wino_first" && (value == 0 || value == 1)) slot = &h->wino_first;
     else if (n == "wino_ps" && value >= 0 && value <= 4) slot = &h->wino_ps;
-    else if (n == "wino_w" && value >= 0 && value <= 3) slot = &h->wino_w;
+    else if (n == "wino_w" && value >= 0 && value <= 4) slot = &h->wino_w;
     else if (n == "splitk_fused" && (value == 0 || value == 1)) slot = &h->splitk_fused;
     else if (n == "splitk_slots" && value >= 1 && value <= 4) slot = &h->splitk_slots;
     else if (n == "splitk_min_steps" && value >= 1 && value <= 9) slot = &h->splitk_min_steps;
@@ -1705,6 +1753,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "splitk" && (value == 0 || value == 1)) slot = &h->splitk;
     else if (n == "tile_h" && (value == 0 || value == 8 || value == 16)) slot = &h->tile_h;
     else if (n == "convt_occ" && (value == 0 || value == 1)) slot = &h->convt_occ;
+    else if (n == "convt_w" && (value == 0 || value == 1)) slot = &h->convt_w;
     else if (n == "fuse_head" && (value == 0 || value == 1)) slot = &h->fuse_head;
     else if (n == "fuse_first" && (value == 0 || value == 1)) slot = &h->fuse_first;
     else if (n == "keep_taps" && (value == 0 || value == 1)) slot = &h->keep_taps;
@@ -1765,6 +1814,7 @@ int og_unet_segment_u8_dev(og_unet* h, const uint8_t* gray, int B, int H, int W,
         for (og_unet* t = h->twin; t && n_lanes < want && n_lanes < n_chunks; t = t->twin) lanes[n_lanes++] = t;
     for (int l = 1; l < n_lanes; ++l)   // every allocation BEFORE the fork: nothing below can fail between fork and join except a launch
         if ((rc = ensure_arena(lanes[l], cb, H, W))) return rc;
+    for (int l = 0; l < n_lanes; ++l) lanes[l]->active_lanes = n_lanes;
     if (n_lanes > 1) HIPCHK(hipEventRecord(h->ev_fork, h->stream));
     int forked = 1;
     for (int l = 1; l < n_lanes && !rc; ++l) {  // a lane's chain must see everything enqueued so far on this stream (area memset, caller's H2D copies)
@@ -1814,6 +1864,7 @@ static int stream_impl(og_unet* h, const uint8_t* frames, const uint8_t* const* 
         for (og_unet* t = h->twin; t && n_lanes < want && n_lanes < n_chunks; t = t->twin) lanes[n_lanes++] = t;
     for (int l = 0; l < n_lanes; ++l)
         if ((rc = ensure_arena(lanes[l], cb, H, W))) return rc;
+    for (int l = 0; l < n_lanes; ++l) lanes[l]->active_lanes = n_lanes;
     const int n_slots = (n_chunks < n_lanes + 2) ? n_chunks : n_lanes + 2;   // one being filled, one per lane computing, one draining
     if ((rc = ensure_ring(h, n_slots, cb, H, W, ch, mask != nullptr, logits != nullptr))) return rc;
     auto& R = h->ring;
@@ -1948,6 +1999,7 @@ int og_unet_forward_f32(og_unet* h, const float* x, int B, int H, int W, float* 
     const int cb = chunk < B ? chunk : B;
     if ((rc = ensure_arena(h, cb, H, W))) return rc;
     const int taps_saved = h->keep_taps;
+    h->active_lanes = 1;
     h->keep_taps = 1;  // the parity/debug entry point keeps every layer-boundary tensor readable
     for (int b0 = 0; b0 < B && !rc; b0 += chunk) {
         const int nb = (B - b0 < chunk) ? B - b0 : chunk;
@@ -2180,6 +2232,7 @@ int og_unet_profile(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, in
     if ((rc = ensure_stage(h, al256((size_t)B * 4)))) return rc;
     std::vector<double> acc;
     std::vector<og_unet::ProfEntry> first;
+    h->active_lanes = 1;   // the profile is one chain on one lane
     for (int r = 0; r < reps; ++r) {
         std::vector<og_unet::ProfEntry> tr;
         h->prof = &tr;
@@ -2230,6 +2283,7 @@ int og_unet_clock_probe(og_unet* h, const uint8_t* gray_dev, int B, int H, int W
     std::vector<og_unet::ProfEntry> tr;
     h->prof = &tr;
     h->probing = true;
+    h->active_lanes = 1;
     pick_chain_form(h, B, H, W);   // the chain the product runs (og_unet_profile's), not whatever form the last call left behind
     rc = enqueue_first(h, KIND_U8, gray_dev, B, H, W);
     if (!rc) rc = enqueue_body(h, B);

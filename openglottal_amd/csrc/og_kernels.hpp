@@ -1929,6 +1929,287 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w(ConvArgs a) {
     }
 }
 
+// POSITION-ROW-SPLIT form of k_conv_wino_w for the deep layers of a one-frame chain (maps of <= 64 x 64 pixels with hundreds of input
+// channels: a 32-window tile's serial loop of Cin / 8 chunks x 16 MFMAs per wave is what bounds them, not the chip).  The same
+// 8 x 16-pixel x 32-channel tiles, but a tile's four position ROWS go to four workgroups (grid.z x 4) and the four positions of a row
+// to the four waves: 4 MFMAs per wave and chunk.  Each wave transforms only its own position -- 4 patch pixels, both axes' signs as
+// fma multipliers (exactly the rounding of k_conv_wino's add / subtract) -- so every accumulator holds the bits k_conv_wino computes.
+// The raw accumulators meet in the split-K workspace as in k_conv_wino_ps, but a tile is 64 KB instead of 256 KB and there are four
+// times as many reducing workgroups: the last of a tile's four workgroups to arrive reads all 16 positions back (16 loads per lane),
+// runs k_conv_wino's output transform and the shared epilogue.  BIT-IDENTICAL to k_conv_wino whatever arrives first.
+//   LDS: raw halo ring 3 x 24 KB (32-channel stages, two ahead) | U ring 9 x 4 KB (a wave's position of an 8-channel chunk, 8 chunks ahead)
+//   vmcnt: counted against a uniform issue pattern (per chunk 1 U piece, per stage 6 raw pieces, out-of-range past the end); the counts
+//   are the smallest the pattern ever leaves behind a piece, so a wait may cover older pieces too, never fewer.
+__global__ __launch_bounds__(256, 1) void k_conv_wino_wp(ConvArgs a) {
+    constexpr int RP = 18, RAW_PIX = 10 * RP, RAW_PIECES = RAW_PIX * 8, RAW_IT = (RAW_PIECES + 255) / 256;   // 180, 1440, 6
+    constexpr int RAW_PAD = RAW_IT * 4096, GSTRIDE = RAW_PIX * 32;
+    constexpr int RS = 3, UD = 8, US = UD + 1, UCH = 4096, UBASE = RS * RAW_PAD;
+    static_assert(UBASE + US * UCH <= 160 * 1024 && 4 * 5120 <= UBASE, "LDS budget / epilogue scratch");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+
+    // grid.z = k_conv_wino_w's z (frame x column tile) x position row: a tile's four workgroups are neighbours in the dispatch order
+    const int prow = (int)blockIdx.z & 3, bz = (int)blockIdx.z >> 2;
+    const int q_ = (a.zdiv == 1) ? bz : (int)(((float)bz + 0.5f) * a.zrcp);
+    const int n_tile = bz - q_ * a.zdiv;
+    const int b = q_;
+    if (b >= a.frames) return;   // every position row of such a tile returns: nobody waits for it
+    const int ty0 = (int)blockIdx.y * 8, tx0 = (int)blockIdx.x * 16;
+    const int tile_id = ((b * a.tiles_y + (int)blockIdx.y) * a.tiles_x + (int)blockIdx.x) * a.zdiv + n_tile;
+    unsigned long long* st = nullptr;   // diagnostic timeline (og_unet_clock_probe only): entry, loop start, loop end, exit (top bit: reducer)
+    if (a.stamps != nullptr) {
+        const unsigned wg = ((unsigned)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        st = a.stamps + 4ull * (wg < 1023u ? wg : 1023u);
+        if (tid == 0) st[0] = __builtin_amdgcn_s_memtime();
+    }
+
+    const int n_st = a.n_chunks, n_ck = 4 * a.n_chunks;
+    const og_i32x4 in_rsrc = og_make_rsrc(a.in + (long long)b * a.in_frame_stride + a.in_ch_off,
+                                          (unsigned)(a.in_frame_stride - a.in_ch_off) * 4u);
+    const og_i32x4 w_rsrc = og_make_rsrc(a.wpk + (long long)n_tile * n_ck * 4096, (unsigned)n_ck * 16384u);
+    const unsigned lds0 = og_lds_addr(smem);
+    unsigned hoff[RAW_IT];   // as k_conv_wino_w<1>
+    {
+        int g = 0, hy = (tid >> 1) / RP, r18 = (tid >> 1) - hy * RP;
+        const int hp = tid & 1;
+#pragma unroll
+        for (int it = 0; it < RAW_IT; ++it) {
+            const int hx = (r18 >= 9) ? 2 * (r18 - 9) + 1 : 2 * r18;
+            const int lg = hp ^ ((hy >> 2) & 1);
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            const bool inb = it * 256 + tid < RAW_PIECES && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            hoff[it] = inb ? (unsigned)((gy * a.W + gx) * a.in_pix_stride * 4 + g * 32 + lg * 16) : OG_OOB;
+            r18 += 128 % RP;
+            hy += 128 / RP;
+            if (r18 >= RP) { r18 -= RP; hy += 1; }
+            if (hy >= 10) { hy -= 10; g += 1; }
+        }
+    }
+    auto raw_piece = [&](int s, int it) {   // stage s -> raw[s % RS]; past the last stage: zero records (zeros, no traffic), same count
+        og_i32x4 rs = in_rsrc;
+        rs.z = (s < n_st) ? in_rsrc.z : 0;
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((s % RS) * RAW_PAD) + wave * 1024);
+        glds16b(hoff[it], rs, (unsigned)s * 128u, base + it * 4096);
+    };
+    auto u_piece = [&](int c) {   // position 4 prow + wave of chunk c -> U[c % US]
+        og_i32x4 ws = w_rsrc;
+        ws.z = (c < n_ck) ? w_rsrc.z : 0;
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + UBASE + (unsigned)((c % US) * UCH) + wave * 1024);
+        glds16b((unsigned)lane * 16u, ws, (unsigned)((c * 16 + 4 * prow + wave) * 1024), base);
+    };
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) raw_piece(0, it);
+#pragma unroll
+    for (int c = 0; c <= UD; ++c) u_piece(c);
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) raw_piece(1, it);
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) raw_piece(2, it);
+
+    // position (prow, wave): B^T d B per axis is x[ia] +- x[ib] with (ia, ib, sign) = (0,2,-) (1,2,+) (2,1,-) (1,3,-)
+    auto ia_of = [](int i) { return (i == 0) ? 0 : (i == 2) ? 2 : 1; };
+    auto ib_of = [](int i) { return (i == 0) ? 2 : (i == 1) ? 2 : (i == 2) ? 1 : 3; };
+    const int ra = ia_of(prow), rb = ib_of(prow), ca = ia_of(wave), cb = ib_of(wave);
+    const float rsgn = (prow == 1) ? 1.0f : -1.0f, csgn = (wave == 1) ? 1.0f : -1.0f;
+    const int wr = li & 3, wc = 2 * (li >> 3) + ((li >> 2) & 1);
+    unsigned rbase[2][2], rcur[2][2];
+#pragma unroll
+    for (int rsel = 0; rsel < 2; ++rsel)
+#pragma unroll
+        for (int csel = 0; csel < 2; ++csel) {
+            const int hy = 2 * wr + (rsel ? rb : ra), pc = csel ? cb : ca;
+            rbase[rsel][csel] = lds0 + (unsigned)((hy * RP + (pc & 1) * 9 + wc + (pc >> 1)) * 32 + ((lh ^ ((hy >> 2) & 1)) << 4));
+            rcur[rsel][csel] = rbase[rsel][csel];
+        }
+    const unsigned ubase = lds0 + UBASE + (unsigned)(wave * 1024 + li * 32 + ((lh ^ ((li >> 3) & 1)) << 4));
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    asm volatile("" : "+a"(acc));
+    f32x4 tv[2], bv[2], rd[2][2];
+    auto fma4 = [](float sgn, f32x4 b_, f32x4 a_) {
+        return f32x4{fmaf(sgn, b_.x, a_.x), fmaf(sgn, b_.y, a_.y), fmaf(sgn, b_.z, a_.z), fmaf(sgn, b_.w, a_.w)};
+    };
+    auto read_raw = [&](int r, int j) { rd[r >> 1][r & 1] = og_lds_read16(rcur[r >> 1][r & 1] + (unsigned)(j * GSTRIDE)); };
+    auto xform = [&](int to) {   // rows first (t = x[ra] +- x[rb] for the two columns), then the column op: k_conv_wino's order
+        const f32x4 ta = fma4(rsgn, rd[1][0], rd[0][0]), tb = fma4(rsgn, rd[1][1], rd[0][1]);
+        tv[to] = fma4(csgn, tb, ta);
+    };
+    auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UD + 2 * RAW_IT) : "memory");   // raw(0) and U(0) landed
+    barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) read_raw(r, 0);
+    bv[0] = og_lds_read16(ubase);
+    xform(0);
+    if (st != nullptr && tid == 0) st[1] = __builtin_amdgcn_s_memtime();
+
+    // one chunk: 4 MFMAs on tv / bv[cur]; behind them the side work of the NEXT chunk (c_rd = 4 s_rd + j_rd), in fixed slots.
+    // MODE 1: same stage; MODE 2: the next chunk opens stage s_rd (barrier, stage s_rd + 2 requested); MODE 0: last chunk
+    auto chunk = [&](int cur, int mode, int s_rd, int j_rd, int c_rd) {
+        const unsigned ucur = ubase + (unsigned)((c_rd % US) * UCH);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tv[cur][e], bv[cur][e], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (mode != 0) {
+                if (e == 0) {
+                    if (mode == 2) {
+                        // raw(s_rd): at least the 3 U pieces of the last three chunks and the next stage's 6 raw pieces are younger
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + RAW_IT) : "memory");
+                        barrier();
+                        const unsigned ring = (unsigned)((s_rd % RS) * RAW_PAD);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) rcur[i >> 1][i & 1] = rbase[i >> 1][i & 1] + ring;
+                    }
+                    // U(c_rd): at least U(c_rd + 1 .. c_rd + UD - 1) and one raw stage are younger
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UD - 1 + RAW_IT) : "memory");
+                    read_raw(0, j_rd);
+                    read_raw(1, j_rd);
+                } else if (e == 1) {
+                    read_raw(2, j_rd);
+                    read_raw(3, j_rd);
+                    bv[cur ^ 1] = og_lds_read16(ucur);
+                } else if (e == 2) {
+                    u_piece(c_rd + UD);
+                    if (mode == 2) { raw_piece(s_rd + 2, 0); raw_piece(s_rd + 2, 1); raw_piece(s_rd + 2, 2); }
+                } else {
+                    xform(cur ^ 1);
+                    if (mode == 2) { raw_piece(s_rd + 2, 3); raw_piece(s_rd + 2, 4); raw_piece(s_rd + 2, 5); }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int s = 0; s + 1 < n_st; ++s) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) chunk(j & 1, 1, s, j + 1, 4 * s + j + 1);
+        chunk(1, 2, s + 1, 0, 4 * s + 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) chunk(j & 1, 1, n_st - 1, j + 1, 4 * (n_st - 1) + j + 1);
+    chunk(1, 0, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the out-of-range tail pieces still write (zeros) into the rings
+    barrier();
+    if (st != nullptr && tid == 0) st[2] = __builtin_amdgcn_s_memtime();
+
+    // ---- raw accumulators out: [window row e][position][lane] x 16 B (registers e, 4 + e, 8 + e, 12 + e), device scope; arrival;
+    //      the last of the tile's four workgroups: k_conv_wino's tail on window row `wave` of all 16 positions ----
+    float* const part = a.partial + (long long)tile_id * 16384 + lane * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        og_store16_dev(part + ((e * 16 + 4 * prow + wave) * 64) * 4, f32x4{acc[e], acc[4 + e], acc[8 + e], acc[12 + e]});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part is written through
+    __syncthreads();
+    int* const flag = (int*)smem;
+    if (tid == 0) *flag = (atomicAdd(a.tile_counter + tile_id, 1) == 3) ? 1 : 0;
+    __syncthreads();
+    if (*(volatile int*)flag == 0) {
+        if (st != nullptr && tid == 0) st[3] = __builtin_amdgcn_s_memtime();
+        return;
+    }
+    __syncthreads();   // the flag word is part of wave 0's epilogue scratch
+    const int ecol = n_tile * 32 + li;
+    const float esc = a.scale[ecol], esh = a.shift[ecol];
+    const __amdgpu_buffer_rsrc_t part_rs = og_rsrc(a.partial + (long long)tile_id * 16384, 65536u);
+    const unsigned part_voff = (unsigned)((wave * 16 * 64 + lane) * 16);
+    f32x16 o;
+    {
+        f32x4 m[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) m[p] = og_load16_dev(part_rs, part_voff, (unsigned)(p * 1024));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // Y = A^T M A exactly as k_conv_wino writes it (its register r = 4 q + wave)
+            float tm[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tm[0][j] = m[0 + j][q] + m[4 + j][q] + m[8 + j][q];
+                tm[1][j] = m[4 + j][q] - m[8 + j][q] - m[12 + j][q];
+            }
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                o[4 * q + 2 * y + 0] = tm[y][0] + tm[y][1] + tm[y][2];
+                o[4 * q + 2 * y + 1] = tm[y][1] - tm[y][2] - tm[y][3];
+            }
+        }
+    }
+    unsigned char* const scr = smem + wave * 5120;
+    if (a.act == 1) conv_epilogue_b<1, 0, 8, 1, false>(a, &o, n_tile, b, ty0, tx0, wave, 0, li, lh, esc, esh, scr);
+    else conv_epilogue_b<1, 0, 8, 0, false>(a, &o, n_tile, b, ty0, tx0, wave, 0, li, lh, esc, esh, scr);
+    if (tid == 0) a.tile_counter[tile_id] = 0;   // ready for the next launch on this stream
+    if (st != nullptr && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st[3] = __builtin_amdgcn_s_memtime() | (1ull << 63);
+    }
+}
+
+// ConvTranspose2d(2f, f, 2, 2) (unet.py:69,82) for launches that cannot fill the chip (one frame per kernel chain: the 16 x 16 map of
+// the deepest level is 2 tiles x 16 column tiles of k_conv_mfma_o / _p, each with a serial loop over 512 input channels).  Same GEMM
+// (N = 4 Cout columns (dy, dx, co)), same k order per output (channel chunks of 32, k groups of 8, the fragment layout's pairs) and
+// the same epilogue as the direct kernels -- bit-identical -- on the finest tiles the MFMA allows: a WAVE owns 32 input pixels
+// (2 rows x 16) x 32 columns, a workgroup four column tiles of the same pixels (the A lines are then shared in the CU's L1).
+// Operands go straight from memory to the fragment registers (16 B per lane, three chunks ahead): at this size an LDS round trip
+// and its barriers cost more than the 32-byte gathers.  Weights: the NT = 1 image of pack_gemm_b (row = column n, slot' = slot ^ (n >> 1 & 7)).
+__global__ __launch_bounds__(256) void k_convt_w(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 5120];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int b = (int)blockIdx.z / a.zdiv;                       // zdiv = column tiles / 4
+    const int n_tile = ((int)blockIdx.z - b * a.zdiv) * 4 + wave;
+    const int ty0 = (int)blockIdx.y * 2, tx0 = (int)blockIdx.x * 16;
+    // A rows: i -> 2x2-window-major pixel order, as every kernel that feeds conv_epilogue_b
+    const int px = tx0 + 2 * (li >> 2) + (li & 1), py = ty0 + ((li >> 1) & 1);
+    const __amdgpu_buffer_rsrc_t in_rs = og_rsrc(a.in + (long long)b * a.in_frame_stride + a.in_ch_off, (unsigned)(a.in_frame_stride - a.in_ch_off) * 4u);
+    const unsigned aoff = (py < a.H && px < a.W) ? (unsigned)(((py * a.W + px) * a.in_pix_stride + 4 * lh) * 4) : OG_OOB;
+    const __amdgpu_buffer_rsrc_t w_rs = og_rsrc(a.wpk + (long long)n_tile * a.n_chunks * 1024, (unsigned)a.n_chunks * 4096u);
+    unsigned boff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) boff[j] = (unsigned)(li * 128 + (((2 * j + lh) ^ ((li >> 1) & 7)) << 4));
+    const int ecol = n_tile * 32 + li;
+    const float esc = a.scale[ecol % a.aff_mod], esh = a.shift[ecol % a.aff_mod];
+
+    f32x4 fa[4][4], fb[4][4];   // [ring slot][k group]
+    auto fetch = [&](int c, int slot) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            fa[slot][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rs, aoff, (unsigned)((c * 32 + 8 * j) * 4), 0));
+            fb[slot][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, boff[j], (unsigned)(c * 4096), 0));
+        }
+    };
+    const int n = a.n_chunks;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        if (c < n) fetch(c, c);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int c0 = 0; c0 < n; c0 += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + k;
+            if (c < n) {
+                if (c + 3 < n) fetch(c + 3, (k + 3) & 3);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 av = fa[k][j], bv = fb[k][j];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+    conv_epilogue_b<1, 1, 8, 0, false, false, 1>(a, &acc, n_tile, b, ty0, tx0, 0, 0, li, lh, esc, esh, smem + wave * 5120);
+}
+
 // Split-precision twin of k_conv_mfma_o (MODE 0: 3x3 conv, MODE 1: 2x2 stride-2 transposed conv): same tiles, halo /
 // weight staging, LDS images, swizzles and fragment addressing; the operands are f16 hi/lo pairs in the H layout and each
 // (chunk, tap) costs 6 x v_mfma_f32_32x32x16_f16 per 32-row sub-tile instead of 16 x v_mfma_f32_32x32x2_f32.  No split-K.

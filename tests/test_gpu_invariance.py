@@ -128,8 +128,8 @@ def test_same_kernels_at_every_micro_batch_size(base):
 
     def form(kernel):
         assert "splitK" not in kernel, kernel
-        if kernel.startswith(("k_conv_wino_ps<", "k_conv_wino_w<")):     # position-split / wave-split launch of the same form (same sums)
-            return "k_conv_wino<" + kernel.split("<")[1].split(",")[0] + ">"
+        if kernel.startswith(("k_conv_wino_ps<", "k_conv_wino_w<", "k_conv_wino_wp<")):     # position-split / wave-split launch of the same form (same sums)
+            return "k_conv_wino<" + kernel.split("<")[1].split(",")[0].rstrip(">") + ">"
         return kernel if kernel.startswith(("k_conv_wino", "k_conv_first")) else "direct:" + kernel.split("<")[1].split(",")[1]   # MODE
 
     k64 = [(p["layer"], form(p["kernel"])) for p in m.profile(d, 64, 256, 256, reps=1)]

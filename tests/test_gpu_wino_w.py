@@ -40,14 +40,18 @@ def base():
 
 
 def test_every_winograd_layer_on_the_wave_split_kernel_is_bit_identical(base):
-    """Forced onto EVERY Winograd layer (WB 1 and WB 2), one to five frames per chain and a chip-filling one, repeated."""
+    """Forced onto EVERY Winograd layer (k_conv_wino_w WB 1 and WB 2; k_conv_wino_wp, position rows on four workgroups, wherever
+    its workspace allows), one to five frames per chain and a chip-filling one, repeated (arrival order varies)."""
     m, fr, masks, areas, logits = base
     try:
-        for force, tag in [(2, ",1>"), (3, ",2>")]:
+        for force, tag in [(2, ",1>"), (3, ",2>"), (4, "p<")]:
             m.set_option("wino_w", force)
             names = _kernels(m, fr, 1, 256, 256)
-            assert sum(k.startswith("k_conv_wino_w<") for k in names) == 17, names
-            assert all(k.endswith(tag) for k in names if k.startswith("k_conv_wino_w<")), names
+            assert sum(k.startswith("k_conv_wino_w") for k in names) == 17, names
+            if force == 4:      # (its workspace holds 1 024 tiles: the 256 x 256 layers fall back to k_conv_wino_w<1> from 3 frames per launch on)
+                assert sum(k.startswith("k_conv_wino_wp<") for k in names) == 17, names
+            else:
+                assert all(k.endswith(tag) for k in names if k.startswith("k_conv_wino_w")), names
             for chunk, n in [(1, 10), (2, 10), (5, 10), (64, 70)]:
                 m.set_chunk(chunk)
                 for rep in range(2):
@@ -64,10 +68,10 @@ def test_automatic_choice_at_one_frame_per_chain(base):
     chain takes the wave-split kernel on the shallow layers; per-frame calls through the reference's entry point too."""
     m, fr, masks, areas, logits = base
     names = _kernels(m, fr, 1, 256, 256)
-    assert sum(k.startswith("k_conv_wino_w<") for k in names) >= 6, names
+    assert sum(k.startswith("k_conv_wino_w") for k in names) >= 6, names
     assert not any("splitK" in k for k in names), names
     names64 = _kernels(m, fr, 64, 256, 256)
-    assert not any(k.startswith(("k_conv_wino_w<", "k_conv_wino_ps<")) for k in names64), names64
+    assert not any(k.startswith(("k_conv_wino_w", "k_conv_wino_ps<")) for k in names64), names64
     try:
         for chunk, lanes in [(1, 1), (1, 3), (3, 2), (16, 0)]:
             m.set_chunk(chunk)
@@ -103,11 +107,43 @@ def test_wave_split_kernel_on_other_shapes(feats, shape):
     assert np.abs(l0[:2] - ref_logits).max() <= 5e-5 * max(1.0, float(np.abs(ref_logits).max()))
     m.set_option("wino_ps", 1)
     seen = 0
-    for force in (1, 2, 3):
+    for force in (1, 2, 3, 4):
         m.set_option("wino_w", force)
         for chunk in (1, 2, 5):
             m.set_chunk(chunk)
             _, a1, l1 = m.segment(fr, want_mask=False, want_logits=True)
             assert np.array_equal(l1, l0) and np.array_equal(a1, a0), (force, chunk, float(np.abs(l1 - l0).max()))
-        seen += sum(k.startswith("k_conv_wino_w<") for k in _kernels(m, fr, 1, H, W))
+        seen += sum(k.startswith("k_conv_wino_w") for k in _kernels(m, fr, 1, H, W))
     assert seen > 0     # the wave-split kernel really ran on this shape
+
+
+def test_transposed_convs_on_wave_tiles_are_bit_identical(base):
+    """k_convt_w (one frame per chain: ConvTranspose2d on 32-pixel x 32-column wave tiles, operands straight to registers) against
+    the direct kernels: the same k order per output and the same epilogue, so logits bit for bit -- at one to five frames per chain,
+    and on a small-width net whose transposed convs have padded channel slots."""
+    m, fr, masks, areas, logits = base
+    assert sum(k.startswith("k_convt_w<") for k in _kernels(m, fr, 1, 256, 256)) >= 3      # (the 128 -> 256 one fills the chip by itself)
+    assert sum(k.startswith("k_convt_w<") for k in _kernels(m, fr, 64, 256, 256)) == 0
+    try:
+        for on in (0, 1):
+            m.set_option("convt_w", on)
+            for chunk in (1, 2, 5):
+                m.set_chunk(chunk)
+                mk, ar, lg = m.segment(fr[:10], want_logits=True)
+                assert np.array_equal(lg, logits[:10]) and np.array_equal(ar, areas[:10]) and np.array_equal(mk, masks[:10]), (on, chunk)
+    finally:
+        m.set_option("convt_w", 1)
+        m.set_chunk(64)
+    for feats, (H, W) in [((4, 8, 16, 32), (64, 96)), ((40, 80), (32, 32)), ((32, 64, 128), (96, 48))]:
+        sd = synth.make_unet_state_dict(feats, seed=H + 3 * W, head_scale=2.0, head_bias=-0.4)
+        s = og.UNet(1, 1, feats)
+        s.load_state_dict(sd)
+        s.to("cuda:0").eval()
+        f = synth.random_gray_frames(3, H, W, seed=W)
+        s.set_chunk(1)
+        s.set_option("convt_w", 0)
+        _, a0, l0 = s.segment(f, want_mask=False, want_logits=True)
+        s.set_option("convt_w", 1)
+        _, a1, l1 = s.segment(f, want_mask=False, want_logits=True)
+        assert np.array_equal(l0, l1) and np.array_equal(a0, a1), (feats, H, W, float(np.abs(l0 - l1).max()))
+        assert any(k.startswith("k_convt_w<") for k in _kernels(s, f, 1, H, W)), (feats, H, W)

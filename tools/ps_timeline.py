@@ -28,5 +28,5 @@ for i, p in enumerate(prof[:-0 or None]):
     t = (v & np.uint64((1 << 63) - 1)).astype(np.float64) / mhz
     t0 = t[:, 0].min()
     pro, loop, tail = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
-    print(f"{p['layer']:28s} {p['kernel']:20s} wgs {len(v):4d} start spread {np.median(t[:,0]-t0):5.2f} us | prologue {np.median(pro):5.2f} | loop {np.median(loop):6.2f} "
-          f"| tail non-reducer {np.median(tail[~red]) if (~red).any() else 0:5.2f} reducer {np.median(tail[red]) if red.any() else 0:5.2f} | last exit {t[:,3].max()-t0:6.2f} us | event {p['ms']*1e3:6.1f} us")
+    print(f"{p['layer']:28s} {p['kernel']:20s} wgs {len(v):4d} | prologue {np.median(pro):5.2f} | loop {np.median(loop):6.2f} "
+          f"| tail non-reducer {np.median(tail[~red]) if (~red).any() else 0:5.2f} reducer {np.median(tail[red]) if red.any() else 0:5.2f} | first entry -> last exit {t[:,3].max()-t0:6.2f} us | event {p['ms']*1e3:6.1f} us")
