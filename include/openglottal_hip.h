@@ -208,6 +208,19 @@ int og_unet_clock_probe_raw(og_unet* h, int entry, unsigned long long* out4x1024
 /* Algorithmic work of one forward at HxW (conv + convT + head MACs x2), for rooflines. */
 double og_unet_flops_per_frame(og_unet* h, int H, int W);
 
+/* Dry run of the kernel chain of one micro-batch (B u8 frames of H x W, areas wanted) for a net of the given widths, WITHOUT a
+ * device: the library's own launch decisions (the code path of og_unet_segment_u8_dev's run_chunk) are executed on a host-only
+ * handle with every launch recorded instead of issued.  `options` = "name=value,name=value" (og_unet_set_option names), `lanes` =
+ * lanes of the call the micro-batch belongs to (1..3: a scheduling hint of the under-filled launches).  `out` receives one line per
+ * launch, "kernel|grid.x|grid.y|grid.z|block|lds_bytes|workspace_bytes|arrival_counters"; returns the number of launches or a
+ * negative error code.  Nothing here has a counterpart in the reference (it launches nothing by hand); it exists so that the bounds
+ * every launch must respect -- og_workspace_limit() -- can be checked for every micro-batch size, layer shape and forced option on a
+ * machine without a GPU (tests/test_launch_plan.py), instead of being found by a faulting kernel. */
+int og_unet_plan(const int* features, int n_levels, int B, int H, int W, int lanes, const char* options, char* out, size_t cap,
+                 long long* arena_bytes);
+/* which: 0 split-K / position-split workspace bytes per lane, 1 arrival counters per lane, 2 largest grid.y / grid.z, 3 LDS bytes per workgroup */
+long long og_workspace_limit(int which);
+
 /* YOLOv8 detector ----------------------------------------------------------
  * Replaces `self.model(frame_bgr, conf=self.conf, verbose=False)` + `boxes.conf.argmax()` /
  * `boxes.xyxy[idx]` of TemporalDetector.detect (openglottal/models/detector.py:58-64), i.e. the

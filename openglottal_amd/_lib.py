@@ -73,6 +73,9 @@ PROTOTYPES = {
                                       C.POINTER(C.c_int)]),
     "og_unet_clock_probe_raw": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "og_unet_flops_per_frame": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
+    "og_unet_plan": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_size_t,
+                               C.POINTER(C.c_longlong)]),
+    "og_workspace_limit": (C.c_longlong, [C.c_int]),
     "og_yolo_create": (C.c_void_p, [C.c_int]),
     "og_yolo_destroy": (None, [C.c_void_p]),
     "og_yolo_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_int]),

@@ -34,6 +34,71 @@ int fail(int code, const std::string& msg) {
 
 inline int cp32(int c) { return (c + 31) / 32 * 32; }
 
+constexpr int kMaxLanes = 3;   // a fourth lane measured slower than three at every micro-batch size
+constexpr size_t kPartialBytes = 64u << 20;  // split-K / position-split workspace per lane (only small launches ever use it)
+constexpr int kTileCounters = 4096;          // arrival counters of the fused reduces per lane (one per tile of a split launch)
+
+// A handle lives on one HIP device; HIP's current device is per host thread.  Every entry point selects the handle's device for
+// the duration of the call and RESTORES the caller's on every exit path (a process that also drives torch on another device must not
+// find its current device changed by a call into this library).
+struct DeviceGuard {
+    int prev = -1;
+    bool restore = false;
+    hipError_t err = hipSuccess;
+    DeviceGuard(int dev, bool skip) {
+        if (skip || dev < 0) return;
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            restore = (err == hipSuccess);
+        }
+    }
+    ~DeviceGuard() {
+        if (restore) (void)hipSetDevice(prev);
+    }
+};
+#define OG_SCOPE(h)                                                                                       \
+    DeviceGuard dg_((h) ? (h)->device : -1, og_skip_device(h));                                           \
+    if (dg_.err != hipSuccess) return fail(OG_EHIP, std::string("selecting the handle's device: ") + hipGetErrorString(dg_.err))
+
+// Dry run of a kernel chain ("plan"): while a recorder is installed on the calling thread, every launch site of the U-Net chain
+// records (kernel, grid, block, LDS bytes, split-K workspace bytes, arrival counters) instead of launching, and no HIP call is made.
+// og_unet_plan() runs the product's own launch decisions this way on a host-only handle, so that their bounds -- grid.z <= 65535,
+// LDS <= 160 KB, workspace <= kPartialBytes, counters <= kTileCounters -- can be walked over every micro-batch size, layer shape and
+// forced option on a machine without a GPU (tests/test_launch_plan.py).
+struct PlanRec {
+    std::string kernel;
+    unsigned gx, gy, gz, block, lds;
+    long long partial_bytes;
+    long long counters;
+};
+struct Plan {
+    std::vector<PlanRec> recs;
+    long long need_partial = 0, need_counters = 0;
+};
+thread_local Plan* g_plan = nullptr;
+inline void plan_need(long long partial_bytes, long long counters) {
+    if (g_plan) {
+        g_plan->need_partial = partial_bytes;
+        g_plan->need_counters = counters;
+    }
+}
+inline void plan_record(const char* kernel, dim3 grid, dim3 block, size_t lds) {
+    g_plan->recs.push_back({kernel, grid.x, grid.y, grid.z, block.x, (unsigned)lds, g_plan->need_partial, g_plan->need_counters});
+    g_plan->need_partial = g_plan->need_counters = 0;
+}
+// every launch of the chain goes through here: a failed launch is reported as OG_EHIP by THIS call (not by a later one)
+#define OG_LAUNCH(kern, grid, block, lds, stream, ...)                                                    \
+    do {                                                                                                  \
+        if (g_plan) {                                                                                     \
+            plan_record(#kern, grid, block, lds);                                                         \
+        } else {                                                                                          \
+            hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                              \
+            hipError_t le_ = hipGetLastError();                                                           \
+            if (le_ != hipSuccess) return fail(OG_EHIP, std::string(#kern) + ": " + hipGetErrorString(le_)); \
+        }                                                                                                 \
+    } while (0)
+
 struct HostTensor {
     std::vector<int64_t> shape;
     std::vector<float> data;
@@ -76,6 +141,7 @@ struct og_unet {
     std::map<std::string, HostTensor> host;
     std::map<std::string, std::vector<int64_t>> expected;
     bool finalized = false;
+    bool host_only = false;   // og_unet_plan: layer shapes and launch decisions only -- no device, no stream, pointers are placeholders
 
     // parameters on device
     float* d_first_w = nullptr;  // [9][Cp0]
@@ -124,6 +190,8 @@ struct og_unet {
     int wino_w = 1;      // under-filled Winograd launches on k_conv_wino_w (the 16 positions over the four waves of a workgroup, finer
                          // tiles) / k_conv_wino_wp (its position rows on four workgroups): bit-identical; 0 off, 1 auto,
                          // 2 / 3 force k_conv_wino_w<1> / <2>, 4 forces k_conv_wino_wp on every Winograd layer (tests, A/B)
+    int inject_fault = 0; // TEST HOOK ("inject_fault" n): the n-th conv launch from now on fails with OG_EHIP after scribbling over the arrival
+                          // counters, as a launch that died half-way would leave them; the error paths must restore them (tests/test_gpu_recovery.py)
     int active_lanes = 1; // lanes of the call in progress (set by the entry points on every lane): scheduling hint for pick_wino_w
     int wino_first = 1;  // Winograd chains: first layer unfused so that the second conv takes k_conv_wino<1>
     bool wino_chain = false;   // (pick_chain_form) wino && precision == 0 && conv_impl == 2
@@ -196,6 +264,8 @@ struct og_unet {
     int h_square = 1;      // split precision, 64-column kernel on 16x16 tiles: 2x2 sub-tiles per wave (fewer LDS reads per MFMA)
     int stream_host = 1;   // og_unet_segment_u8 goes through the streaming engine (0: one-shot staging of the whole batch)
 };
+
+inline bool og_skip_device(const og_unet* h) { return !h || h->host_only || !h->finalized; }
 
 namespace {
 
@@ -322,6 +392,11 @@ int build_conv(og_unet* h, ConvLayer& L, const std::string& wkey, const std::str
     L.Cin_p = (int)cin_map.size();
     L.Cout_p = cp32(Cout);
     L.NT = (L.Cout_p % 64 == 0) ? 2 : 1;
+    if (h->host_only) {   // shapes only: every image a launch decision asks for "exists"
+        L.d_w = L.d_w_h = L.d_ww = L.d_scale = L.d_shift = (float*)8;
+        L.d_w1 = L.d_ww1 = (L.NT == 2) ? (float*)8 : nullptr;
+        return OG_OK;
+    }
     const auto& w = h->host.at(wkey).data;  // [Cout][Cin][3][3]
     auto at = [&](int n, int k, int t) -> float {
         const int ci = cin_map[k];
@@ -350,6 +425,10 @@ int build_convT(og_unet* h, ConvLayer& L, const std::string& p, int Cin, int Cou
     L.Cin_p = cp32(Cin);
     L.Cout_p = cp32(Cout);
     L.NT = 2;  // N = 4*Cout_p is a multiple of 128
+    if (h->host_only) {
+        L.d_w = L.d_w_h = L.d_w1 = L.d_scale = L.d_shift = (float*)8;
+        return OG_OK;
+    }
     const auto& w = h->host.at(p + ".weight").data;  // [Cin][Cout][2][2]
     const auto& bias = h->host.at(p + ".bias").data;
     const int Cop = L.Cout_p;
@@ -395,6 +474,69 @@ void drop_graphs(og_unet* h) {
     h->graphs.clear();
 }
 
+// After a failed call: the fused reduces (k_conv_wino_ps / _wp, split-K) rely on arrival counters that are zero at launch and are
+// re-zeroed only by a tile's LAST arriver, so a chain that stopped half-way (failed launch, failed capture, device error) may leave
+// some behind -- later calls would then never elect a reducer for those tiles, or elect it early, and return stale activations with
+// rc 0.  Every error path therefore clears the lane's counters (in stream order) before the error is reported.
+void reset_counters(og_unet* h) {
+    if (h->host_only || !h->d_tile_counter || !h->stream) return;
+    (void)hipMemsetAsync(h->d_tile_counter, 0, kTileCounters * sizeof(int), h->stream);
+}
+
+// Layout of the activation arena for (B, H, W): views as OFFSETS from the arena base (pure arithmetic, no device)
+struct ArenaPlan {
+    std::vector<Act> A, CAT, P, UA, UB;
+    Act BA, BB;
+    size_t total = 0;
+};
+ArenaPlan arena_layout(const og_unet* h, int B, int H, int W) {
+    const int L = h->L;
+    ArenaPlan p;
+    p.A.resize(L); p.CAT.resize(L); p.P.resize(L); p.UA.resize(L); p.UB.resize(L);
+    auto plan = [&](Act& a, int C, int hh, int ww) {
+        a.C = C;
+        a.H = hh;
+        a.W = ww;
+        a.p = (float*)p.total;  // offset for now
+        p.total += ((size_t)B * hh * ww * C * sizeof(float) + 255) / 256 * 256;
+    };
+    for (int i = 0; i < L; ++i) {
+        const int C = cp32(h->features[i]);
+        const int hh = H >> i, ww = W >> i;
+        plan(p.A[i], C, hh, ww);
+        plan(p.CAT[i], 2 * C, hh, ww);
+        plan(p.P[i], C, hh >> 1, ww >> 1);
+        plan(p.UA[i], C, hh, ww);
+        plan(p.UB[i], C, hh, ww);
+    }
+    const int Cb = cp32(2 * h->features[L - 1]);
+    plan(p.BA, Cb, H >> L, W >> L);
+    plan(p.BB, Cb, H >> L, W >> L);
+    return p;
+}
+void adopt_arena(og_unet* h, ArenaPlan& p, void* base, int B, int H, int W) {
+    auto fix = [&](Act& a) { a.p = (float*)((char*)base + (size_t)a.p); };
+    for (int i = 0; i < h->L; ++i) {
+        fix(p.A[i]);
+        fix(p.CAT[i]);
+        fix(p.P[i]);
+        fix(p.UA[i]);
+        fix(p.UB[i]);
+    }
+    fix(p.BA);
+    fix(p.BB);
+    h->A = p.A;
+    h->CAT = p.CAT;
+    h->P = p.P;
+    h->UA = p.UA;
+    h->UB = p.UB;
+    h->BA = p.BA;
+    h->BB = p.BB;
+    h->capB = B;
+    h->aH = H;
+    h->aW = W;
+}
+
 // Activation arena.  Capacity is kept in BYTES: a call at another frame size (or a smaller micro-batch) re-plans the layer
 // buffers inside the existing allocation instead of freeing and reallocating it, and captured hipGraphs stay valid as long as
 // the allocation does (their key carries the plan's frame capacity), so a stream of mixed frame sizes does not thrash
@@ -403,29 +545,8 @@ int ensure_arena(og_unet* h, int B, int H, int W) {
     const bool same_shape = (H == h->aH && W == h->aW);
     if (h->arena && same_shape && B <= h->capB) return OG_OK;
     if (same_shape && B < h->capB) B = h->capB;
-    const int L = h->L;
-    std::vector<Act> A(L), CAT(L), P(L), UA(L), UB(L);
-    Act BA, BB;
-    size_t total = 0;
-    auto plan = [&](Act& a, int C, int hh, int ww) {
-        a.C = C;
-        a.H = hh;
-        a.W = ww;
-        a.p = (float*)total;  // offset for now
-        total += ((size_t)B * hh * ww * C * sizeof(float) + 255) / 256 * 256;
-    };
-    for (int i = 0; i < L; ++i) {
-        const int C = cp32(h->features[i]);
-        const int hh = H >> i, ww = W >> i;
-        plan(A[i], C, hh, ww);
-        plan(CAT[i], 2 * C, hh, ww);
-        plan(P[i], C, hh >> 1, ww >> 1);
-        plan(UA[i], C, hh, ww);
-        plan(UB[i], C, hh, ww);
-    }
-    const int Cb = cp32(2 * h->features[L - 1]);
-    plan(BA, Cb, H >> L, W >> L);
-    plan(BB, Cb, H >> L, W >> L);
+    ArenaPlan p = arena_layout(h, B, H, W);
+    const size_t total = p.total;
     if (h->stream) HIPCHK(hipStreamSynchronize(h->stream));   // the old plan may still be in use
     if (!h->arena || total > h->arena_bytes) {
         drop_graphs(h);   // they hold pointers into the old allocation
@@ -440,26 +561,7 @@ int ensure_arena(og_unet* h, int B, int H, int W) {
     // Padded channels of the convT half etc. are always written (zero weights -> exact zeros), but clear on every re-plan
     // so that debug reads of never-touched bytes are defined.
     HIPCHK(hipMemsetAsync(h->arena, 0, total, h->stream));
-    auto fix = [&](Act& a) { a.p = (float*)((char*)h->arena + (size_t)a.p); };
-    for (int i = 0; i < L; ++i) {
-        fix(A[i]);
-        fix(CAT[i]);
-        fix(P[i]);
-        fix(UA[i]);
-        fix(UB[i]);
-    }
-    fix(BA);
-    fix(BB);
-    h->A = A;
-    h->CAT = CAT;
-    h->P = P;
-    h->UA = UA;
-    h->UB = UB;
-    h->BA = BA;
-    h->BB = BB;
-    h->capB = B;
-    h->aH = H;
-    h->aW = W;
+    adopt_arena(h, p, h->arena, B, H, W);
     return OG_OK;
 }
 
@@ -480,8 +582,7 @@ int launch_conv_t(og_unet* h, const ConvArgs& a, int n_ntiles) {
     constexpr int PAD = (MODE == 0) ? 1 : 0;
     constexpr int lds = 2 * (16 + 2 * PAD) * (TH + 2 * PAD) * 128 + 2 * 32 * NT * 128;
     const unsigned grid = (unsigned)(a.n_spatial * n_ntiles);
-    hipLaunchKernelGGL((k_conv_mfma<NT, MODE, TH>), dim3(grid), dim3(256), lds, h->stream, a);
-    HIPCHK(hipGetLastError());
+    OG_LAUNCH((k_conv_mfma<NT, MODE, TH>), dim3(grid), dim3(256), lds, h->stream, a);
     return OG_OK;
 }
 
@@ -497,8 +598,6 @@ struct LaunchCtx {
     int xcd_group = 1;   // occupancy kernel: frame-interleaved grid.z so that a tile's column tiles share an XCD
 };
 
-constexpr int kMaxLanes = 3;   // a fourth lane measured slower than three at every micro-batch size
-constexpr size_t kPartialBytes = 64u << 20;  // split-K workspace (only small launches ever use it)
 
 // Split-K factor for a launch of `n_items` tiles over `n_chunks` 32-channel chunks: only when the
 // launch would leave >= 3/4 of the workgroup slots empty (small-batch / latency mode), so that
@@ -526,7 +625,7 @@ int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     static_assert(lds >= 4 * 5120, "the epilogue's per-wave scratch needs 20 KB");
     ConvArgs a = a_in;
     a.stamps = nullptr;  // the probe buffer is sized for the persistent kernel's grid; this kernel's timeline is tools/ubench/occ_timeline
-    if (a.n_spatial * n_ntiles > 4096) a.tile_counter = nullptr;
+    if (a.n_spatial * n_ntiles > kTileCounters) a.tile_counter = nullptr;
     if ((MODE == 2 || MODE == 3) && a.tile_counter == nullptr) a.ksplit = 1;   // these modes split K with the fused reduce only
     const int frames = a.n_spatial / (a.tiles_x * a.tiles_y);
     a.zdiv = n_ntiles * a.ksplit;
@@ -542,12 +641,13 @@ int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     a.zrcp = 1.0f / (float)(a.zdiv * G);
     if ((long long)groups * G * a.zdiv > 65535) return fail(OG_EINVAL, "micro-batch too large for one launch (grid.z): lower the chunk size");
     if (a.ksplit == 1) a.tile_counter = nullptr;
-    hipLaunchKernelGGL((k_conv_mfma_o<NT, MODE, TH, OCC>), dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), lds, c.stream, a);
-    HIPCHK(hipGetLastError());
+    if (a.ksplit > 1)   // raw accumulators of every K part (4 waves x MS sub-tiles x 16 registers x 64 lanes), arrivals per tile
+        plan_need((long long)a.n_spatial * n_ntiles * a.ksplit * 4 * (((TH / 2) / (4 / NT)) * 16 * 64) * 4,
+                  a.tile_counter ? (long long)a.n_spatial * n_ntiles : 0);
+    OG_LAUNCH((k_conv_mfma_o<NT, MODE, TH, OCC>), dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), lds, c.stream, a);
     if constexpr (MODE == 0 || MODE == 1) {
         if (a.ksplit > 1 && a.tile_counter == nullptr) {
-            hipLaunchKernelGGL((k_splitk_epilogue<NT, MODE, TH>), dim3(a.n_spatial * n_ntiles), dim3(256), 4 * 5120, c.stream, a);
-            HIPCHK(hipGetLastError());
+            OG_LAUNCH((k_splitk_epilogue<NT, MODE, TH>), dim3(a.n_spatial * n_ntiles), dim3(256), 4 * 5120, c.stream, a);
         }
     }
     return OG_OK;
@@ -574,8 +674,7 @@ int launch_conv_wino(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {  
     const int G = 1 << a.zgroup_shift, groups = (frames + G - 1) / G;
     a.zrcp = 1.0f / (float)(a.zdiv * G);
     if ((long long)groups * G * a.zdiv > 65535) return fail(OG_EINVAL, "micro-batch too large for one launch (grid.z): lower the chunk size");
-    hipLaunchKernelGGL(k_conv_wino<NT>, dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), wino_lds<NT>(), c.stream, a);
-    HIPCHK(hipGetLastError());
+    OG_LAUNCH(k_conv_wino<NT>, dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), wino_lds<NT>(), c.stream, a);
     return OG_OK;
 }
 
@@ -598,8 +697,8 @@ int launch_conv_wino_ps(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) 
     a.zrcp = 1.0f / (float)a.zdiv;
     if ((long long)frames * a.zdiv * (16 / PN) > 65535) return fail(OG_EINVAL, "k_conv_wino_ps: grid.z");
     constexpr int lds = wino_ps_lds<NT, PN>();
-    hipLaunchKernelGGL((k_conv_wino_ps<NT, PN>), dim3(a.tiles_x, a.tiles_y, frames * a.zdiv * (16 / PN)), dim3(256), lds, c.stream, a);
-    HIPCHK(hipGetLastError());
+    plan_need((long long)a.n_spatial * n_ntiles * (16 * 4 * 1024 * 4), (long long)a.n_spatial * n_ntiles);
+    OG_LAUNCH((k_conv_wino_ps<NT, PN>), dim3(a.tiles_x, a.tiles_y, frames * a.zdiv * (16 / PN)), dim3(256), lds, c.stream, a);
     return OG_OK;
 }
 
@@ -630,8 +729,7 @@ int launch_conv_wino_w(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     const int G = 1 << a.zgroup_shift, groups = (frames + G - 1) / G;
     a.zrcp = 1.0f / (float)(a.zdiv * G);
     if ((long long)groups * G * a.zdiv > 65535) return fail(OG_EINVAL, "micro-batch too large for one launch (grid.z): lower the chunk size");
-    hipLaunchKernelGGL(k_conv_wino_w<WB>, dim3(a.tiles_x, gy, groups * G * a.zdiv), dim3(256), wino_w_lds<WB>(), c.stream, a);
-    HIPCHK(hipGetLastError());
+    OG_LAUNCH(k_conv_wino_w<WB>, dim3(a.tiles_x, gy, groups * G * a.zdiv), dim3(256), wino_w_lds<WB>(), c.stream, a);
     return OG_OK;
 }
 
@@ -648,8 +746,8 @@ int launch_conv_wino_wp(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) 
     a.zgroup_shift = 0;
     a.zrcp = 1.0f / (float)a.zdiv;
     if ((long long)frames * a.zdiv * 4 > 65535) return fail(OG_EINVAL, "k_conv_wino_wp: grid.z");
-    hipLaunchKernelGGL(k_conv_wino_wp, dim3(a.tiles_x, a.tiles_y, frames * a.zdiv * 4), dim3(256), kWinoWpLds, c.stream, a);
-    HIPCHK(hipGetLastError());
+    plan_need((long long)a.n_spatial * n_ntiles * 65536, (long long)a.n_spatial * n_ntiles);
+    OG_LAUNCH(k_conv_wino_wp, dim3(a.tiles_x, a.tiles_y, frames * a.zdiv * 4), dim3(256), kWinoWpLds, c.stream, a);
     return OG_OK;
 }
 
@@ -658,7 +756,7 @@ int launch_conv_h(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {   //
     constexpr int lds = conv_o_lds<NT, MODE, TH>();
     ConvArgs a = a_in;
     a.stamps = nullptr;
-    if (SQ || a.tile_counter == nullptr || a.partial == nullptr || a.n_spatial * n_ntiles > 4096) a.ksplit = 1;   // fused reduce only
+    if (SQ || a.tile_counter == nullptr || a.partial == nullptr || a.n_spatial * n_ntiles > kTileCounters) a.ksplit = 1;   // fused reduce only
     const int frames = a.n_spatial / (a.tiles_x * a.tiles_y);
     a.zdiv = n_ntiles * a.ksplit;
     a.frames = frames;
@@ -672,8 +770,7 @@ int launch_conv_h(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {   //
     const int G = 1 << a.zgroup_shift, groups = (frames + G - 1) / G;
     a.zrcp = 1.0f / (float)(a.zdiv * G);
     if ((long long)groups * G * a.zdiv > 65535) return fail(OG_EINVAL, "micro-batch too large for one launch (grid.z): lower the chunk size");
-    hipLaunchKernelGGL((k_conv_mfma_h<NT, MODE, TH, OCC, false, SQ>), dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), lds, c.stream, a);
-    HIPCHK(hipGetLastError());
+    OG_LAUNCH((k_conv_mfma_h<NT, MODE, TH, OCC, false, SQ>), dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), lds, c.stream, a);
     return OG_OK;
 }
 
@@ -684,11 +781,10 @@ int launch_conv_p(const LaunchCtx& c, const ConvArgs& a, int n_ntiles) {
     const int slots = c.n_cu * ((lds > 80 * 1024) ? 1 : c.wg_per_cu);
     const int rounds = (n_items + slots - 1) / slots;
     const int grid = (n_items + rounds - 1) / rounds;  // <= slots, balanced: every workgroup gets rounds or rounds-1 items
-    hipLaunchKernelGGL((k_conv_mfma_p<NT, MODE, TH, TPS>), dim3(grid), dim3(256), lds, c.stream, a, n_items);
-    HIPCHK(hipGetLastError());
+    if (a.ksplit > 1) plan_need((long long)n_items * 4 * (((TH / 2) / (4 / NT)) * 16 * 64) * 4, 0);
+    OG_LAUNCH((k_conv_mfma_p<NT, MODE, TH, TPS>), dim3(grid), dim3(256), lds, c.stream, a, n_items);
     if (a.ksplit > 1) {
-        hipLaunchKernelGGL((k_splitk_epilogue<NT, MODE, TH>), dim3(a.n_spatial * n_ntiles), dim3(256), 4 * 5120, c.stream, a);
-        HIPCHK(hipGetLastError());
+        OG_LAUNCH((k_splitk_epilogue<NT, MODE, TH>), dim3(a.n_spatial * n_ntiles), dim3(256), 4 * 5120, c.stream, a);
     }
     return OG_OK;
 }
@@ -766,7 +862,7 @@ int init_kernel_attrs() {  // must not run inside a stream capture
 int pick_wino_w(const og_unet* h, const ConvLayer& L, int B, int H, int W) {
     if (!h->wino_w || (L.NT == 2 && L.d_ww1 == nullptr) || H % 8 || W % 16) return 0;
     const long long w1 = (long long)B * (W / 16) * (H / 8) * (L.Cout_p / 32);   // 8 x 16-pixel x 32-channel tiles
-    const bool wp_ok = h->d_partial != nullptr && h->d_tile_counter != nullptr && w1 <= 1024 && w1 * 65536 <= (long long)kPartialBytes;
+    const bool wp_ok = h->d_partial != nullptr && h->d_tile_counter != nullptr && w1 <= kTileCounters && w1 * 65536 <= (long long)kPartialBytes;
     if (h->wino_w == 2) return 1;
     if (h->wino_w == 3) return (H % 16 == 0) ? 2 : 1;
     if (h->wino_w == 4) return wp_ok ? 4 : 1;
@@ -784,6 +880,10 @@ int pick_wino_w(const og_unet* h, const ConvLayer& L, int B, int H, int W) {
 // in: activation view + channel offset/count; out likewise; pool optional
 int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off, const Act& out, int out_off, const Act* pool) {
     constexpr int TH = 8;
+    if (h->inject_fault > 0 && --h->inject_fault == 0 && !g_plan) {
+        if (h->d_tile_counter) (void)hipMemsetAsync(h->d_tile_counter, 0x01, kTileCounters * sizeof(int), h->stream);
+        return fail(OG_EHIP, "injected launch failure (option inject_fault)");
+    }
     // 16x16 tiles only for the 3x3 convs of the persistent kernel, and only when every tile is full
     const bool full16 = (L.mode == 0 && in.H % 16 == 0 && in.W % 16 == 0);
     bool big = full16 && h->tile_h == 16 && (h->conv_impl == 1 || h->conv_impl == 2);
@@ -970,7 +1070,7 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
             // beat 512 of the split form on the 256x256 layers, 64 lose to 256 on the 128x128 ones).
             const long long wgs = (long long)a.n_spatial * n_ntiles;
             int pn = 0;
-            if (h->wino_ps && h->d_partial != nullptr && h->d_tile_counter != nullptr && wgs * 4 <= h->n_cu && wgs <= 4096 &&
+            if (h->wino_ps && h->d_partial != nullptr && h->d_tile_counter != nullptr && wgs * 4 <= h->n_cu && wgs <= kTileCounters &&
                 (size_t)wgs * (16 * 4 * 1024 * sizeof(float)) <= kPartialBytes) {
                 pn = (wgs * 4 >= h->n_cu) ? 4 : (wgs * 8 >= h->n_cu) ? 2 : 1;
                 if (h->wino_ps > 1) pn = (h->wino_ps == 2) ? 4 : (h->wino_ps == 3) ? 2 : 1;   // forced (tests, A/B)
@@ -1058,9 +1158,8 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         a.frames = B;
         if ((long long)B * a.zdiv > 65535) return fail(OG_EINVAL, "k_convt_w: grid.z");
         prof_begin(h, L.name, "k_convt_w<1,1,8>", flt);
-        hipLaunchKernelGGL(k_convt_w, dim3((in.W + 15) / 16, (in.H + 1) / 2, B * a.zdiv), dim3(256), 0, h->stream, a);
+        OG_LAUNCH(k_convt_w, dim3((in.W + 15) / 16, (in.H + 1) / 2, B * a.zdiv), dim3(256), 0, h->stream, a);
         prof_end(h);
-        HIPCHK(hipGetLastError());
         return OG_OK;
     }
     if (impl == 0) {
@@ -1093,19 +1192,18 @@ int enqueue_first(og_unet* h, int kind, const void* in, int B, int H, int W) {
     prof_begin(h, "downs.0.net.0.weight", kind == KIND_U8 ? "k_conv_first<u8>" : "k_conv_first<f32>",
                2.0 * B * H * W * 9.0 * h->features[0]);
     if (kind == KIND_U8 && h->precision == 1)
-        hipLaunchKernelGGL((k_conv_first<uint8_t, true>), dim3(B * tiles), dim3(256), 0, h->stream, (const uint8_t*)in, o.p,
+        OG_LAUNCH((k_conv_first<uint8_t, true>), dim3(B * tiles), dim3(256), 0, h->stream, (const uint8_t*)in, o.p,
                            h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride(), h->d_range);
     else if (kind == KIND_U8)
-        hipLaunchKernelGGL(k_conv_first<uint8_t>, dim3(B * tiles), dim3(256), 0, h->stream, (const uint8_t*)in, o.p,
+        OG_LAUNCH(k_conv_first<uint8_t>, dim3(B * tiles), dim3(256), 0, h->stream, (const uint8_t*)in, o.p,
                            h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride(), (int*)nullptr);
     else if (h->precision == 1)
-        hipLaunchKernelGGL((k_conv_first<float, true>), dim3(B * tiles), dim3(256), 0, h->stream, (const float*)in, o.p,
+        OG_LAUNCH((k_conv_first<float, true>), dim3(B * tiles), dim3(256), 0, h->stream, (const float*)in, o.p,
                            h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride(), h->d_range);
     else
-        hipLaunchKernelGGL(k_conv_first<float>, dim3(B * tiles), dim3(256), 0, h->stream, (const float*)in, o.p,
+        OG_LAUNCH(k_conv_first<float>, dim3(B * tiles), dim3(256), 0, h->stream, (const float*)in, o.p,
                            h->d_first_w, h->d_first_scale, h->d_first_shift, H, W, Cp0, o.C, o.frame_stride(), (int*)nullptr);
     prof_end(h);
-    HIPCHK(hipGetLastError());
     return OG_OK;
 }
 
@@ -1160,11 +1258,10 @@ int enqueue_first_fused(og_unet* h, const uint8_t* gray, int B, int H, int W) {
     a.frames = B;
     if (h->precision == 1) a.prio_mode = h->prio_mode;
     if (h->precision == 1)
-        hipLaunchKernelGGL((k_conv_mfma_h<1, 0, 8, 3, true>), dim3(a.tiles_x, a.tiles_y, B), dim3(256), lds, h->stream, a);
+        OG_LAUNCH((k_conv_mfma_h<1, 0, 8, 3, true>), dim3(a.tiles_x, a.tiles_y, B), dim3(256), lds, h->stream, a);
     else
-        hipLaunchKernelGGL((k_conv_mfma_o<1, 0, 8, 3, true>), dim3(a.tiles_x, a.tiles_y, B), dim3(256), lds, h->stream, a);
+        OG_LAUNCH((k_conv_mfma_o<1, 0, 8, 3, true>), dim3(a.tiles_x, a.tiles_y, B), dim3(256), lds, h->stream, a);
     prof_end(h);
-    HIPCHK(hipGetLastError());
     return OG_OK;
 }
 
@@ -1204,7 +1301,7 @@ int enqueue_last_with_head(og_unet* h, int B, float thr, const int32_t* boxes, u
                            !pick_wino_w(h, h->dec_b[L - 1], B, u.H, u.W);   // k_conv_wino_w counts per 8x16 tile, like the direct kernel
     const int tiles = wino_last ? (u.W / 16) * (u.H / 32) : ((u.W + 15) / 16) * ((u.H + 7) / 8);
     const size_t need = (size_t)B * tiles * 4;
-    if (area && need > h->counts_cap) {
+    if (area && need > h->counts_cap && !g_plan) {
         if (h->d_counts) {
             HIPCHK(hipStreamSynchronize(h->stream));
             HIPCHK(hipFree(h->d_counts));
@@ -1223,8 +1320,7 @@ int enqueue_last_with_head(og_unet* h, int B, float thr, const int32_t* boxes, u
     h->fuse.active = false;
     if (rc) return rc;
     if (area) {
-        hipLaunchKernelGGL(k_sum_counts, dim3(B), dim3(256), 0, h->stream, h->d_counts, tiles * 4, area);
-        HIPCHK(hipGetLastError());
+        OG_LAUNCH(k_sum_counts, dim3(B), dim3(256), 0, h->stream, h->d_counts, tiles * 4, area);
     }
     return OG_OK;
 }
@@ -1235,13 +1331,12 @@ int enqueue_head(og_unet* h, int B, int H, int W, float thr, const int32_t* boxe
     const int bpf = (HW + 1023) / 1024;
     prof_begin(h, "head", "k_head", 2.0 * B * HW * h->features[0]);
     if (h->precision == 1)
-        hipLaunchKernelGGL(k_head<true>, dim3(B * bpf), dim3(256), 0, h->stream, u.p, u.frame_stride(), u.C, h->d_head_w,
+        OG_LAUNCH(k_head<true>, dim3(B * bpf), dim3(256), 0, h->stream, u.p, u.frame_stride(), u.C, h->d_head_w,
                            h->head_bias, cp32(h->features[0]), HW, W, thr, boxes, logits, mask, area, bpf);
     else
-        hipLaunchKernelGGL(k_head<false>, dim3(B * bpf), dim3(256), 0, h->stream, u.p, u.frame_stride(), u.C, h->d_head_w,
+        OG_LAUNCH(k_head<false>, dim3(B * bpf), dim3(256), 0, h->stream, u.p, u.frame_stride(), u.C, h->d_head_w,
                            h->head_bias, cp32(h->features[0]), HW, W, thr, boxes, logits, mask, area, bpf);
     prof_end(h);
-    HIPCHK(hipGetLastError());
     return OG_OK;
 }
 
@@ -1312,7 +1407,6 @@ int check_range(og_unet* h) {
 int check_shape(og_unet* h, int B, int H, int W) {
     if (!h) return fail(OG_EINVAL, "null handle");
     if (!h->finalized) return fail(OG_ESTATE, "og_unet_finalize() has not been called");
-    HIPCHK(hipSetDevice(h->device));   // the caller may be another host thread than the one that built the handle
     if (B < 0 || H <= 0 || W <= 0) return fail(OG_EINVAL, "bad B/H/W");
     const int m = 1 << h->L;
     if (H % m || W % m)
@@ -1523,12 +1617,17 @@ og_unet* og_unet_create(const int* features, int n_levels, int in_ch, int out_ch
 
 void og_unet_destroy(og_unet* h) {
     if (!h) return;
+    DeviceGuard dg_(h->device, og_skip_device(h));   // frees and stream teardown on the handle's device, the caller's restored
     if (h->twin) {
         og_unet_destroy(h->twin);
         h->twin = nullptr;
     }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
+    if (h->host_only) {   // placeholders only: nothing to release on any device
+        delete h;
+        return;
+    }
     if (!h->is_twin) {  // a twin borrows every weight pointer from its owner
         for (auto* v : {&h->enc_a, &h->enc_b, &h->up_t, &h->dec_a, &h->dec_b})
             for (auto& l : *v) free_layer(l);
@@ -1590,32 +1689,37 @@ int og_unet_finalize(og_unet* h) {
     std::string missing;
     for (auto& kv : h->expected)
         if (!h->host.count(kv.first)) missing += (missing.empty() ? "" : ", ") + kv.first;
-    if (!missing.empty()) return fail(OG_EINVAL, "missing key(s) in state_dict: " + missing);
+    if (!missing.empty() && !h->host_only) return fail(OG_EINVAL, "missing key(s) in state_dict: " + missing);
 
-    {
+    const int L = h->L;
+    int rc;
+    if (!h->host_only) {
         int dev = 0;
         hipDeviceProp_t prop;
         HIPCHK(hipGetDevice(&dev));
         HIPCHK(hipGetDeviceProperties(&prop, dev));
         h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         h->device = dev;
+        HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&h->ev0));
+        HIPCHK(hipEventCreate(&h->ev1));
+        HIPCHK(hipMalloc((void**)&h->d_zero, 4096));
+        HIPCHK(hipMemset(h->d_zero, 0, 4096));
+        HIPCHK(hipMalloc((void**)&h->d_partial, kPartialBytes));
+        HIPCHK(hipMalloc((void**)&h->d_tile_counter, kTileCounters * sizeof(int)));
+        HIPCHK(hipMemset(h->d_tile_counter, 0, kTileCounters * sizeof(int)));
+        HIPCHK(hipHostMalloc((void**)&h->h_range, sizeof(int), hipHostMallocMapped));
+        *h->h_range = 0;
+        HIPCHK(hipHostGetDevicePointer((void**)&h->d_range, h->h_range, 0));
+        if ((rc = init_kernel_attrs())) return rc;
+    } else {   // og_unet_plan: an MI355X's CU count, placeholder pointers
+        h->n_cu = 256;
+        h->d_zero = (float*)8;
+        h->d_partial = (float*)8;
+        h->d_tile_counter = (int*)8;
+        h->d_first_w = h->d_first_scale = h->d_first_shift = h->d_head_w = (float*)8;
     }
-    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreate(&h->ev0));
-    HIPCHK(hipEventCreate(&h->ev1));
-    HIPCHK(hipMalloc((void**)&h->d_zero, 4096));
-    HIPCHK(hipMemset(h->d_zero, 0, 4096));
-    HIPCHK(hipMalloc((void**)&h->d_partial, kPartialBytes));
-    HIPCHK(hipMalloc((void**)&h->d_tile_counter, 4096 * sizeof(int)));
-    HIPCHK(hipMemset(h->d_tile_counter, 0, 4096 * sizeof(int)));
-    HIPCHK(hipHostMalloc((void**)&h->h_range, sizeof(int), hipHostMallocMapped));
-    *h->h_range = 0;
-    HIPCHK(hipHostGetDevicePointer((void**)&h->d_range, h->h_range, 0));
-
-    const int L = h->L;
-    int rc;
-    if ((rc = init_kernel_attrs())) return rc;
-    {  // first layer: [Cout][1][3][3] -> [9][Cp0]
+    if (!h->host_only) {  // first layer: [Cout][1][3][3] -> [9][Cp0]
         const int f0 = h->features[0], Cp0 = cp32(f0);
         const auto& w = h->host.at("downs.0.net.0.weight").data;
         std::vector<float> w9((size_t)9 * Cp0, 0.f), sc, sh;
@@ -1655,7 +1759,7 @@ int og_unet_finalize(og_unet* h) {
         if ((rc = build_conv(h, h->dec_a[j], pd + ".net.0.weight", pd + ".net.1", 2 * f, f, m))) return rc;
         if ((rc = build_conv(h, h->dec_b[j], pd + ".net.3.weight", pd + ".net.4", f, f, ident_map(f)))) return rc;
     }
-    {
+    if (!h->host_only) {
         const int f0 = h->features[0], Cp0 = cp32(f0);
         std::vector<float> hw(Cp0, 0.f);
         const auto& w = h->host.at("head.weight").data;
@@ -1693,20 +1797,28 @@ int og_unet_finalize(og_unet* h) {
         t->device = h->device;
         prev->twin = t;
         prev = t;
+        if (h->host_only) {
+            t->host_only = true;
+            t->d_partial = (float*)8;
+            t->d_tile_counter = (int*)8;
+            continue;
+        }
         HIPCHK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreate(&t->ev0));
         HIPCHK(hipEventCreate(&t->ev1));
         HIPCHK(hipMalloc((void**)&t->d_partial, kPartialBytes));
-        HIPCHK(hipMalloc((void**)&t->d_tile_counter, 4096 * sizeof(int)));
-        HIPCHK(hipMemset(t->d_tile_counter, 0, 4096 * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&t->d_tile_counter, kTileCounters * sizeof(int)));
+        HIPCHK(hipMemset(t->d_tile_counter, 0, kTileCounters * sizeof(int)));
         HIPCHK(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
     }
+    if (h->host_only) return OG_OK;
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     return OG_OK;
 }
 
 int og_unet_reserve(og_unet* h, int frames_per_launch, int H, int W) {
+    OG_SCOPE(h);
     int rc = check_shape(h, frames_per_launch, H, W);
     if (rc) return rc;
     if (frames_per_launch < 1) return fail(OG_EINVAL, "frames_per_launch must be >= 1");
@@ -1731,6 +1843,7 @@ int og_unet_set_graphs(og_unet* h, int enable) {
 
 int og_unet_set_option(og_unet* h, const char* name, int value) {
     if (!h || !name) return fail(OG_EINVAL, "null argument");
+    OG_SCOPE(h);
     const std::string n(name);
     int* slot = nullptr;
     if (n == "conv_impl" && value >= 0 && value <= 3) slot = &h->conv_impl;
@@ -1743,6 +1856,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "wino_first" && (value == 0 || value == 1)) slot = &h->wino_first;
     else if (n == "wino_ps" && value >= 0 && value <= 4) slot = &h->wino_ps;
     else if (n == "wino_w" && value >= 0 && value <= 4) slot = &h->wino_w;
+    else if (n == "inject_fault" && value >= 0 && value <= 1000) slot = &h->inject_fault;
     else if (n == "splitk_fused" && (value == 0 || value == 1)) slot = &h->splitk_fused;
     else if (n == "splitk_slots" && value >= 1 && value <= 4) slot = &h->splitk_slots;
     else if (n == "splitk_min_steps" && value >= 1 && value <= 9) slot = &h->splitk_min_steps;
@@ -1768,13 +1882,13 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
         drop_graphs(h);
         *slot = value;
     }
-    if (h->twin) return og_unet_set_option(h->twin, name, value);
+    if (h->twin && n != "inject_fault") return og_unet_set_option(h->twin, name, value);   // (the test hook arms the first lane only)
     return OG_OK;
 }
 
 int og_unet_sync(og_unet* h) {
     if (!h || !h->stream) return fail(OG_ESTATE, "handle not finalized");
-    HIPCHK(hipSetDevice(h->device));
+    OG_SCOPE(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     return check_range(h);
 }
@@ -1796,6 +1910,7 @@ int og_timer_stop(og_unet* h, float* ms) {
 
 int og_unet_segment_u8_dev(og_unet* h, const uint8_t* gray, int B, int H, int W, float thr, const int32_t* boxes,
                            uint8_t* mask, int32_t* area, float* logits) {
+    OG_SCOPE(h);
     int rc = check_shape(h, B, H, W);
     if (rc) return rc;
     if (!gray && B > 0) return fail(OG_EINVAL, "gray is null");
@@ -1838,6 +1953,10 @@ int og_unet_segment_u8_dev(og_unet* h, const uint8_t* gray, int B, int H, int W,
     }
     if (rc) {
         g_err = err.empty() ? g_err : err;
+        for (int l = 0; l < n_lanes; ++l) {
+            reset_counters(lanes[l]);
+            if (l > 0) (void)hipStreamSynchronize(lanes[l]->stream);
+        }
         (void)hipStreamSynchronize(h->stream);   // error path only: nothing of this call is in flight when the error is reported
     }
     return rc;
@@ -1846,6 +1965,7 @@ int og_unet_segment_u8_dev(og_unet* h, const uint8_t* gray, int B, int H, int W,
 // The frame loop with the video on the HOST (features.py:226,234-245), streamed: see og_unet::Ring.
 static int stream_impl(og_unet* h, const uint8_t* frames, const uint8_t* const* frame_ptrs, int B, int H, int W, int ch, float thr,
                        const int32_t* boxes, uint8_t* mask, int32_t* area, float* logits) {
+    OG_SCOPE(h);
     int rc = check_shape(h, B, H, W);
     if (rc) return rc;
     if (ch != 1 && ch != 3) return fail(OG_EINVAL, "channels must be 1 (gray) or 3 (BGR)");
@@ -1940,7 +2060,10 @@ static int stream_impl(og_unet* h, const uint8_t* frames, const uint8_t* const* 
     if (rc) {
         const std::string err = g_err;
         (void)hipStreamSynchronize(R.s_h2d);
-        for (int l = 0; l < n_lanes; ++l) (void)hipStreamSynchronize(lanes[l]->stream);
+        for (int l = 0; l < n_lanes; ++l) {
+            reset_counters(lanes[l]);
+            (void)hipStreamSynchronize(lanes[l]->stream);
+        }
         (void)hipStreamSynchronize(R.s_d2h);
         for (auto& s : R.slots) s.b0 = -1;
         g_err = err;
@@ -1963,6 +2086,7 @@ int og_unet_segment_u8(og_unet* h, const uint8_t* gray, int B, int H, int W, flo
                        uint8_t* mask, int32_t* area, float* logits) {
     if (h && h->stream_host) return stream_impl(h, gray, nullptr, B, H, W, 1, thr, boxes, mask, area, logits);
     // one-shot staging of the whole batch ("stream" option 0; kept as the reference the streaming path is tested against)
+    OG_SCOPE(h);
     int rc = check_shape(h, B, H, W);
     if (rc) return rc;
     if (B == 0) return OG_OK;
@@ -1986,6 +2110,7 @@ int og_unet_segment_u8(og_unet* h, const uint8_t* gray, int B, int H, int W, flo
 }
 
 int og_unet_forward_f32(og_unet* h, const float* x, int B, int H, int W, float* logits) {
+    OG_SCOPE(h);
     int rc = check_shape(h, B, H, W);
     if (rc) return rc;
     if (B == 0) return OG_OK;
@@ -2007,7 +2132,13 @@ int og_unet_forward_f32(og_unet* h, const float* x, int B, int H, int W, float* 
                        (float*)(s + o_out) + b0 * HW);
     }
     h->keep_taps = taps_saved;
-    if (rc) return rc;
+    if (rc) {
+        const std::string err = g_err;
+        reset_counters(h);
+        (void)hipStreamSynchronize(h->stream);
+        g_err = err;
+        return rc;
+    }
     HIPCHK(hipMemcpyAsync(logits, s + o_out, B * HW * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return check_range(h);
@@ -2015,7 +2146,7 @@ int og_unet_forward_f32(og_unet* h, const float* x, int B, int H, int W, float* 
 
 int og_mask_area_dev(og_unet* h, const uint8_t* mask, int B, int H, int W, const int32_t* boxes, int32_t* area) {
     if (!h || !h->finalized) return fail(OG_ESTATE, "handle not finalized");
-    HIPCHK(hipSetDevice(h->device));
+    OG_SCOPE(h);
     if (!mask || !area || B < 0 || H <= 0 || W <= 0) return fail(OG_EINVAL, "bad argument");
     if (B == 0) return OG_OK;
     HIPCHK(hipMemsetAsync(area, 0, (size_t)B * 4, h->stream));
@@ -2027,7 +2158,7 @@ int og_mask_area_dev(og_unet* h, const uint8_t* mask, int B, int H, int W, const
 
 int og_bgr2gray_dev(og_unet* h, const uint8_t* bgr, int B, int H, int W, uint8_t* gray) {
     if (!h || !h->finalized) return fail(OG_ESTATE, "handle not finalized");
-    HIPCHK(hipSetDevice(h->device));
+    OG_SCOPE(h);
     if (!bgr || !gray || B < 0 || H <= 0 || W <= 0) return fail(OG_EINVAL, "bad argument");
     const long long n = (long long)B * H * W;
     if (n == 0) return OG_OK;
@@ -2039,7 +2170,7 @@ int og_bgr2gray_dev(og_unet* h, const uint8_t* bgr, int B, int H, int W, uint8_t
 int og_canvas_letterbox_u8_dev(og_unet* h, const uint8_t* packed, const int64_t* offsets, const int32_t* shapes, int B, int channels,
                                int size, const int32_t* geom, int value, uint8_t* out) {
     if (!h || !h->finalized) return fail(OG_ESTATE, "handle not finalized");
-    HIPCHK(hipSetDevice(h->device));
+    OG_SCOPE(h);
     if (B < 0 || size <= 0 || (channels != 1 && channels != 3) || value < 0 || value > 255) return fail(OG_EINVAL, "bad argument");
     if (B == 0) return OG_OK;
     if (!packed || !offsets || !shapes || !geom || !out) return fail(OG_EINVAL, "null buffer");
@@ -2061,7 +2192,7 @@ int og_canvas_letterbox_u8_dev(og_unet* h, const uint8_t* packed, const int64_t*
 int og_canvas_letterbox_u8(og_unet* h, const uint8_t* packed, const int64_t* offsets, const int32_t* shapes, int B, int channels, int size,
                            const int32_t* geom, int value, uint8_t* out) {
     if (!h || !h->finalized) return fail(OG_ESTATE, "handle not finalized");
-    HIPCHK(hipSetDevice(h->device));
+    OG_SCOPE(h);
     if (B < 0 || size <= 0 || (channels != 1 && channels != 3)) return fail(OG_EINVAL, "bad argument");
     if (B == 0) return OG_OK;
     if (!packed || !offsets || !shapes || !geom || !out) return fail(OG_EINVAL, "null buffer");
@@ -2092,7 +2223,7 @@ int og_canvas_letterbox_u8(og_unet* h, const uint8_t* packed, const int64_t* off
 
 int og_mask_stats_dev(og_unet* h, const uint8_t* pred, const uint8_t* gt, int B, int H, int W, const int32_t* boxes, int32_t* stats) {
     if (!h || !h->finalized) return fail(OG_ESTATE, "handle not finalized");
-    HIPCHK(hipSetDevice(h->device));
+    OG_SCOPE(h);
     if (!pred || !gt || !stats || B < 0 || H <= 0 || W <= 0) return fail(OG_EINVAL, "bad argument");
     if (B == 0) return OG_OK;
     HIPCHK(hipMemsetAsync(stats, 0, (size_t)B * 12, h->stream));
@@ -2104,6 +2235,7 @@ int og_mask_stats_dev(og_unet* h, const uint8_t* pred, const uint8_t* gt, int B,
 
 int og_unet_segment_crops_u8_dev(og_unet* h, const uint8_t* gray, int B, int H, int W, const int32_t* boxes, const int32_t* geom,
                                  int size, float thr, uint8_t* tiles_scratch, uint8_t* tile_masks_scratch, uint8_t* out_masks) {
+    OG_SCOPE(h);
     int rc = check_shape(h, B, size, size);
     if (rc) return rc;
     if (B == 0) return OG_OK;
@@ -2128,6 +2260,7 @@ int og_unet_segment_crops_u8_dev(og_unet* h, const uint8_t* gray, int B, int H, 
 
 int og_unet_segment_crops_u8(og_unet* h, const uint8_t* gray, int B, int H, int W, const int32_t* boxes, const int32_t* geom, int size,
                              float thr, uint8_t* out_masks) {
+    OG_SCOPE(h);
     int rc = check_shape(h, B, size, size);
     if (rc) return rc;
     if (B == 0) return OG_OK;
@@ -2224,6 +2357,7 @@ int og_unet_get_activation(og_unet* h, const char* name, int B, float* out, size
 
 int og_unet_profile(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, int reps, int max_entries, char* layers,
                     char* kernels, float* ms, double* flops, int* n_entries) {
+    OG_SCOPE(h);
     int rc = check_shape(h, B, H, W);
     if (rc) return rc;
     if (!gray_dev || B < 1 || reps < 1 || !layers || !kernels || !ms || !flops || !n_entries)
@@ -2272,6 +2406,7 @@ int og_unet_profile(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, in
 }
 
 int og_unet_clock_probe(og_unet* h, const uint8_t* gray_dev, int B, int H, int W, int max_entries, double* mhz, int* n_entries) {
+    OG_SCOPE(h);
     int rc = check_shape(h, B, H, W);
     if (rc) return rc;
     if (!gray_dev || !mhz || !n_entries || B < 1) return fail(OG_EINVAL, "bad argument");
@@ -2323,6 +2458,53 @@ int og_unet_clock_probe_raw(og_unet* h, int entry, unsigned long long* out4x1024
     HIPCHK(hipMemcpy(out4x1024, h->d_stamps + (size_t)entry * 4096, 4096 * 8, hipMemcpyDeviceToHost));
     return OG_OK;
 }
+
+int og_unet_plan(const int* features, int n_levels, int B, int H, int W, int lanes, const char* options, char* out, size_t cap,
+                 long long* arena_bytes) {
+    if (!out || cap == 0 || B < 1) return fail(OG_EINVAL, "bad argument");
+    og_unet* h = og_unet_create(features, n_levels, 1, 1);
+    if (!h) return OG_EINVAL;
+    h->host_only = true;
+    int rc = og_unet_finalize(h);
+    if (!rc) rc = check_shape(h, B, H, W);
+    std::string opt = options ? options : "";
+    for (size_t p0 = 0; !rc && p0 < opt.size();) {   // "name=value,name=value"
+        size_t p1 = opt.find(',', p0);
+        if (p1 == std::string::npos) p1 = opt.size();
+        const std::string kv = opt.substr(p0, p1 - p0);
+        const size_t eq = kv.find('=');
+        if (eq == std::string::npos) rc = fail(OG_EINVAL, "option without '=': " + kv);
+        else rc = og_unet_set_option(h, kv.substr(0, eq).c_str(), atoi(kv.c_str() + eq + 1));
+        p0 = p1 + 1;
+    }
+    Plan plan;
+    if (!rc) {
+        ArenaPlan ap = arena_layout(h, B, H, W);
+        if (arena_bytes) *arena_bytes = (long long)ap.total;
+        adopt_arena(h, ap, (void*)4096, B, H, W);   // a placeholder base: nothing dereferences it in a dry run
+        h->active_lanes = lanes < 1 ? 1 : lanes;
+        g_plan = &plan;
+        // the product's chain for one micro-batch of u8 frames with areas wanted (run_chunk without the hipGraph plumbing)
+        pick_chain_form(h, B, H, W);
+        const bool ff = can_fuse_first(h, KIND_U8, B, H, W), fuse = can_fuse_head(h);
+        rc = ff ? enqueue_first_fused(h, (const uint8_t*)4096, B, H, W) : enqueue_first(h, KIND_U8, (const void*)4096, B, H, W);
+        if (!rc) rc = enqueue_body(h, B, fuse, ff);
+        if (!rc) rc = fuse ? enqueue_last_with_head(h, B, 0.5f, nullptr, nullptr, (int32_t*)4096, nullptr)
+                           : enqueue_head(h, B, H, W, 0.5f, nullptr, nullptr, (int32_t*)4096, nullptr);
+        g_plan = nullptr;
+    }
+    og_unet_destroy(h);
+    if (rc) return rc;
+    std::string txt;
+    for (auto& r : plan.recs)
+        txt += r.kernel + "|" + std::to_string(r.gx) + "|" + std::to_string(r.gy) + "|" + std::to_string(r.gz) + "|" + std::to_string(r.block) + "|" +
+               std::to_string(r.lds) + "|" + std::to_string(r.partial_bytes) + "|" + std::to_string(r.counters) + "\n";
+    if (txt.size() + 1 > cap) return fail(OG_EINVAL, "plan text does not fit the buffer");
+    memcpy(out, txt.c_str(), txt.size() + 1);
+    return (int)plan.recs.size();
+}
+
+long long og_workspace_limit(int which) { return which == 0 ? (long long)kPartialBytes : which == 1 ? kTileCounters : which == 2 ? 65535 : 160 * 1024; }
 
 double og_unet_flops_per_frame(og_unet* h, int H, int W) {
     if (!h) return 0.0;

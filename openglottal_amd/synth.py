@@ -153,6 +153,27 @@ def degraded_glottis_frames(n_patients: int = 2, n_frames: int = 12, seed: int =
     return out, gt
 
 
+def detuned_weights(sd: dict[str, np.ndarray], amplitude: float = 0.8, seed: int = 31337) -> dict[str, np.ndarray]:
+    """A DE-TUNED copy of the trained fixture's net (tests/golden/unet_trained_full.npz), derived without storing a byte: every
+    convolution-kernel element is multiplied by 1 + amplitude * u, u uniform in (-1, 1) from a seeded generator, in float64, rounded
+    once to float32.  Two things come with it.  (1) FULL f32 MANTISSAS: the stored kernels are float16-representable, so the Winograd
+    weight transform G g G^T is (nearly) exact in f32 for them, which it is not for a real float32 checkpoint
+    (scripts/train_unet.py:204-208).  (2) A net that is UNSURE: the trained net's logits jump by several units from one pixel to the
+    next (a few pixels below 1e-2 in a hundred frames); the de-tuned one hovers near zero over whole regions -- thousands of pixels
+    with |logit| < 1e-2, hundreds below 1e-3, a dozen inside the reference's own noise band -- which is where another summation
+    order flips mask pixels and changes area integers.  Regenerated identically by the fixture's generator (which feeds it to the
+    reference, tests/golden/gen_golden.py) and by the tests (which feed it to the oracle and to this library)."""
+    out = {}
+    for i, k in enumerate(sorted(sd)):
+        v = sd[k]
+        if v.ndim >= 2 and v.dtype != np.int64:
+            u = np.random.RandomState(seed + i).uniform(-1.0, 1.0, size=v.shape)
+            out[k] = (v.astype(np.float64) * (1.0 + u * amplitude)).astype(np.float32)
+        else:
+            out[k] = v.astype(np.float32) if v.dtype == np.float16 else v
+    return out
+
+
 def full128_frames() -> tuple[np.ndarray, np.ndarray]:
     """The 128 frames of the bench-configuration fixture (tests/golden/unet_full128.npz): the 80-frame structured
     GIRAFE stand-in (4 "patients" x 20 frames, ``glottis_frames(4, 20, seed=99)``) followed by frames 0..47 of the

@@ -293,6 +293,62 @@ def gen_trained_full(UNet, unet_segment_frame, dice, iou, dice_loss, meta, steps
     print("trained full: mean dice", ev_dice.mean(), "areas", ev_areas[:10], "min|logit|", np.abs(flat).min(), "n<1e-3:", len(near))
 
 
+def gen_trained_hard(UNet, unet_segment_frame, dice, iou, meta) -> None:
+    """(10) HARD exact fixture: the trained full-width net of (9), DE-TUNED (`synth.detuned_weights`: every kernel element times
+    1 + 0.8 u, regenerated on both sides: full f32 mantissas -- a real checkpoint is full float32, `scripts/train_unet.py:204-208` --
+    and a net that is unsure over whole regions), evaluated by the reference's `unet_segment_frame` on (9)'s 104 frames: thousands of
+    pixels with |logit| < 1e-2, hundreds below 1e-3, some inside the reference's own noise band.  Stored: bit-packed masks, integer
+    areas, sampled logits, Dice / IoU vs GT, per-frame min |logit|, and every pixel with |logit| < 1e-3 (frame, pixel, logit) so that
+    a test can apply the flip rule from the reference's numbers alone.  No weights are stored (they are (9)'s).
+    (Soft-edged / low-contrast FRAMES alone do not do it: the trained net answers them with "no glottis", logits <= -5 everywhere.)"""
+    import torch
+
+    from openglottal_amd import synth
+
+    g9 = np.load(os.path.join(HERE, "unet_trained_full.npz"))
+    feats = tuple(int(f) for f in g9["features"])
+    sd = synth.detuned_weights({k[2:]: g9[k] for k in g9.files if k.startswith("W:")})
+    n_full = sum(int(np.any(v.view(np.uint32) & 0x1FFF)) for v in sd.values() if v.ndim >= 2)   # kernels that now use the low 13 bits
+    tm = UNet(1, 1, feats)
+    tm.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    tm.eval()
+    dev = torch.device("cpu")
+    ev_x, ev_y = synth.glottis_frames(4, 20, seed=99)
+    hx, hy = synth.degraded_glottis_frames()
+    ev_x, ev_y = np.concatenate([ev_x, hx]), np.concatenate([ev_y, hy])
+    NF = len(ev_x)
+    ev_masks = np.stack([unet_segment_frame(f, tm, dev) for f in ev_x])
+    ev_logits = np.empty((NF, 256, 256), np.float32)
+    with torch.no_grad():
+        for i in range(NF):
+            ev_logits[i] = tm(torch.from_numpy(ev_x[i:i + 1].astype("float32") / 255.0).unsqueeze(1)).numpy()[0, 0]
+    assert np.array_equal(ev_masks > 0, ev_logits > 0)
+    flat = ev_logits.reshape(NF, -1)
+    near = np.argwhere(np.abs(flat) < 1e-3)
+    n2 = int((np.abs(flat) < 1e-2).sum())
+    assert n2 >= 1000 and len(near) >= 50, (n2, len(near))      # the fixture is hard, or it is not regenerated
+    samp = np.random.RandomState(10).choice(256 * 256, size=1024, replace=False).astype(np.int32)
+    ev_areas = np.array([int(np.sum(m > 0)) for m in ev_masks], dtype=np.int64)
+    ev_dice = np.array([dice(m, g_) for m, g_ in zip(ev_masks, ev_y)])
+    ev_iou = np.array([iou(m, g_) for m, g_ in zip(ev_masks, ev_y)])
+    np.savez_compressed(
+        os.path.join(HERE, "unet_trained_hard.npz"),
+        features=np.array(feats),
+        masks_packed=np.stack([packbits(m) for m in ev_masks]),
+        areas=ev_areas, dice_vs_gt=ev_dice, iou_vs_gt=ev_iou,
+        sample_idx=samp, logits_samples=flat[:, samp].astype(np.float32),
+        abs_logit_min=np.abs(flat).min(axis=1),
+        near_zero_frame=near[:, 0].astype(np.int32), near_zero_pixel=near[:, 1].astype(np.int32),
+        near_zero_logit=flat[near[:, 0], near[:, 1]].astype(np.float32),
+    )
+    meta["trained_hard"] = {"frames": "(9)'s 104: 80 clean + 24 degraded", "weights": "unet_trained_full.npz kernels x (1 + 0.8 u), seed 31337",
+                            "kernels_with_full_mantissa": n_full, "n_abs_logit_lt_1e2": n2, "n_abs_logit_lt_1e3": int(len(near)),
+                            "n_abs_logit_lt_1e4": int((np.abs(flat) < 1e-4).sum()), "abs_logit_min": float(np.abs(flat).min()),
+                            "mean_dice": float(ev_dice.mean()), "areas_first8": ev_areas[:8].tolist(),
+                            "foreground_fraction": float((ev_logits > 0).mean())}
+    print("trained hard:", meta["trained_hard"])
+
+
 def main() -> None:
     install_placeholders()
     import torch
@@ -318,6 +374,8 @@ def main() -> None:
             gen_full128(UNet, unet_segment_frame, dice, iou, meta)
         elif which == "self_noise":
             gen_self_noise(UNet, meta)
+        elif which == "trained_hard":
+            gen_trained_hard(UNet, unet_segment_frame, dice, iou, meta)
         elif which in ("trained_full", "trained_full_eval"):
             torch.set_num_threads(int(os.environ.get("OG_GEN_THREADS", "8")))
             gen_trained_full(UNet, unet_segment_frame, dice, iou, dice_loss, meta, steps=int(os.environ.get("OG_GEN_STEPS", "400")),
@@ -536,6 +594,7 @@ def main() -> None:
     gen_full128(UNet, unet_segment_frame, dice, iou, meta)
     gen_self_noise(UNet, meta)
     gen_trained_full(UNet, unet_segment_frame, dice, iou, dice_loss, meta, steps=400)
+    gen_trained_hard(UNet, unet_segment_frame, dice, iou, meta)
 
     with open(os.path.join(HERE, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1)

@@ -186,3 +186,67 @@ def test_trained_full_width_net_exact_in_bench_configuration(golden_dir):
     for i in (3, 85, 97):
         assert np.array_equal(og.unet_segment_frame(frames[i], m, "cuda:0") > 0, ref[i] > 0), i
     print(f"trained full-width: 104 frames exact; max sampled |dlogit| {err:.2e}; smallest |reference logit| {float(g['abs_logit_min'].min()):.2e}")
+
+
+def test_hard_detuned_net_flip_rule_and_exact_frames_in_bench_configuration(golden_dir):
+    """an exact-match fixture that is HARD.  tests/golden/unet_trained_hard.npz = the reference's
+    `unet_segment_frame` on 104 frames through the trained net DE-TUNED by `synth.detuned_weights` (full f32 mantissas in every
+    kernel; logits hovering near zero over whole regions: 2 489 pixels with |logit| < 1e-2, 248 below 1e-3, 26 below 1e-4, the
+    smallest 3.6e-7).  bench.py's configuration (64 frames per chain, two lanes, graphs, Winograd form asserted):
+      * a mask pixel may differ from the reference only where the REFERENCE's logit is within BAND (the reference's own run-to-run
+        noise, unet_full128_self_noise.npz) of zero -- the flip rule, applied from the fixture's own list of near-zero pixels;
+      * every frame whose smallest |reference logit| is above BAND must match exactly: every pixel, the area integer;
+      * sampled logits within BAND (x the logit scale);
+      * one frame per chain (the wave-split / position-row-split kernels) returns the 64-frame launches' bits."""
+    import torch
+
+    g = np.load(os.path.join(golden_dir, "unet_trained_hard.npz"))
+    g9 = np.load(os.path.join(golden_dir, "unet_trained_full.npz"))
+    feats = tuple(int(f) for f in g["features"])
+    sd = synth.detuned_weights({k[2:]: g9[k] for k in g9.files if k.startswith("W:")})
+    m = og.UNet(1, 1, feats)
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    m.set_chunk(64)
+    m.set_graphs(True)
+    m.set_option("dual", 1)
+    clean, _ = synth.glottis_frames(4, 20, seed=99)
+    hard, _ = synth.degraded_glottis_frames()
+    frames = np.concatenate([clean, hard])
+    n = len(frames)
+    assert n == len(g["areas"]) == 104
+    assert int((g["abs_logit_min"] < 1e-3).sum()) >= 20 and len(g["near_zero_logit"]) >= 50      # the fixture IS hard
+    dev = torch.device("cuda", 0)
+    fdev = torch.from_numpy(frames).to(dev)
+    area = torch.zeros(n, dtype=torch.int32, device=dev)
+    mask = torch.zeros((n, 256, 256), dtype=torch.uint8, device=dev)
+    logits = torch.zeros((n, 256, 256), dtype=torch.float32, device=dev)
+    m.segment_dev(fdev, n, 256, 256, area, mask_dev=mask, logits_dev=logits)
+    m.sync()
+    mk, ar, lg = mask.cpu().numpy(), area.cpu().numpy().astype(np.int64), logits.cpu().numpy()
+    kernels = [p["kernel"] for p in m.profile(fdev, 64, 256, 256, reps=1)]
+    assert kernels.count("k_conv_wino<2>") == 14 and kernels.count("k_conv_wino<1>") == 3, kernels
+    ref = np.unpackbits(g["masks_packed"], axis=1)[:, :65536].reshape(n, 256, 256)
+    nz = {(int(f), int(p)): float(v) for f, p, v in zip(g["near_zero_frame"], g["near_zero_pixel"], g["near_zero_logit"])}
+    flips = np.argwhere(((mk > 0) != (ref > 0)).reshape(n, -1))
+    for f, p in flips:
+        assert abs(nz.get((int(f), int(p)), 1.0)) <= BAND, (int(f), int(p), nz.get((int(f), int(p))))
+    per_frame_flips = np.bincount(flips[:, 0], minlength=n) if len(flips) else np.zeros(n, np.int64)
+    assert np.all(np.abs(ar - g["areas"]) <= per_frame_flips)
+    assert np.array_equal(ar, (mk > 0).reshape(n, -1).sum(1))
+    safe = g["abs_logit_min"] > BAND
+    assert int(safe.sum()) >= 80, int(safe.sum())
+    assert per_frame_flips[safe].sum() == 0 and np.array_equal(ar[safe], g["areas"][safe])       # exact wherever the margins allow
+    scale = max(1.0, float(np.abs(g["logits_samples"]).max()))
+    err = float(np.abs(lg.reshape(n, -1)[:, g["sample_idx"]] - g["logits_samples"]).max())
+    assert err <= BAND * scale, (err, scale)
+    in_band = int(sum(abs(v) <= BAND for v in g["near_zero_logit"]))
+    # one frame per chain and the reference's per-frame entry point: the same bits as the 64-frame launches
+    m.set_chunk(1)
+    mk1, ar1, lg1 = m.segment(frames[:24], want_logits=True)
+    assert np.array_equal(lg1, lg[:24]) and np.array_equal(ar1, ar[:24]) and np.array_equal(mk1, mk[:24])
+    for i in (3, 85, 97):
+        assert np.array_equal(og.unet_segment_frame(frames[i], m, "cuda:0"), mk[i]), i
+    print(f"hard de-tuned net: {len(flips)} flipped pixels of {n * 65536} (all where the reference's |logit| <= BAND = {BAND:.3e}; {in_band} reference "
+          f"pixels lie inside the band), {int((ar != g['areas']).sum())} of {n} areas differ, {int(safe.sum())} frames with margins above the band exact; "
+          f"max sampled |dlogit| {err:.2e} at logit scale {scale:.1f}")

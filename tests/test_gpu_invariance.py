@@ -149,6 +149,7 @@ def test_position_split_launches_are_bit_identical(base):
     m, fr, masks, areas, logits = base
     n = 12
     try:
+        m.set_option("wino_w", 0)     # (round 4's default hands these launches to k_conv_wino_w / _wp: tests/test_gpu_wino_w.py)
         for ps, tag in [(0, None), (1, "auto"), (2, ",4>"), (3, ",2>"), (4, ",1>")]:
             m.set_option("wino_ps", ps)
             for chunk in (1, 3):
@@ -167,6 +168,7 @@ def test_position_split_launches_are_bit_identical(base):
                 assert n_ps >= 10 and all(k.endswith(tag) for k in names if k.startswith("k_conv_wino_ps")), names
     finally:
         m.set_option("wino_ps", 1)
+        m.set_option("wino_w", 1)
         m.set_chunk(64)
 
 
@@ -185,6 +187,7 @@ def test_position_split_on_other_shapes(feats, shape):
     m.load_state_dict(sd)
     m.to("cuda:0").eval()
     fr = synth.random_gray_frames(5, H, W, seed=H + W)
+    m.set_option("wino_w", 0)
     m.set_option("wino_ps", 0)
     m.set_chunk(5)
     _, a0, l0 = m.segment(fr, want_mask=False, want_logits=True)

@@ -132,6 +132,32 @@ def test_trained_full_width_fixture_subset(golden_dir):
         assert int((masks[j] > 0).sum()) == int(g["areas"][i])
 
 
+def test_hard_detuned_fixture_subset(golden_dir):
+    """The oracle against the HARD fixture (the trained net de-tuned by `synth.detuned_weights`: full f32 mantissas, thousands of
+    pixels with |logit| < 1e-2; evaluated by the reference's `unet_segment_frame`): 10 of the 104 frames here, all on the GPU.  The
+    oracle runs the reference's own op sequence through the same oneDNN build, so masks and areas come out exact on this machine;
+    the flip rule (reference |logit| <= band) is what a different summation order is held to."""
+    g = np.load(os.path.join(golden_dir, "unet_trained_hard.npz"))
+    g9 = np.load(os.path.join(golden_dir, "unet_trained_full.npz"))
+    band = float(np.load(os.path.join(golden_dir, "unet_full128_self_noise.npz"))["band"])
+    assert int((np.abs(g["near_zero_logit"]) < 1e-3).sum()) >= 50 and float(g["abs_logit_min"].min()) < 1e-5
+    sd = synth.detuned_weights({k[2:]: g9[k] for k in g9.files if k.startswith("W:")})
+    assert all(v.dtype == np.float32 for k, v in sd.items() if v.ndim >= 2)
+    assert sum(int(np.any(v.view(np.uint32) & 0x1FFF)) for v in sd.values() if v.ndim >= 2) == 23      # every kernel uses the low mantissa bits
+    clean, _ = synth.glottis_frames(4, 20, seed=99)
+    hard, _ = synth.degraded_glottis_frames()
+    frames = np.concatenate([clean, hard])
+    sel = [0, 17, 41, 66, 79, 80, 86, 91, 97, 103]
+    masks, logits = O.segment_frames(sd, frames[sel], backend="torch")
+    nz = {(int(f), int(p)): float(v) for f, p, v in zip(g["near_zero_frame"], g["near_zero_pixel"], g["near_zero_logit"])}
+    for j, i in enumerate(sel):
+        scale = max(1.0, float(np.abs(g["logits_samples"][i]).max()))
+        assert np.abs(logits[j].ravel()[g["sample_idx"]] - g["logits_samples"][i]).max() <= LOGIT_TOL * scale, i
+        flips = np.flatnonzero(((masks[j] > 0) != (unpack(g["masks_packed"][i]) > 0)).ravel())
+        assert all(abs(nz.get((i, int(p)), 1.0)) <= band for p in flips), (i, flips[:5])
+        assert abs(int((masks[j] > 0).sum()) - int(g["areas"][i])) <= len(flips)
+
+
 def test_reference_self_noise_band_is_what_the_tests_use(golden_dir):
     """The flip band of the full-width GPU tests is the reference's own run-to-run difference, stored next to the fixture."""
     import json
