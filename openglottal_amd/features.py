@@ -86,7 +86,13 @@ def load_frames_bgr(source) -> list[np.ndarray]:
 
 
 BLOCK = 1024  # frames handed to the device engine per call (host side only: the engine itself streams micro-batches)
-GATED_BLOCK = 128   # gated pipeline: the detector pass of block k + 1 runs (worker thread, own handle and stream) under the U-Net pass of block k
+GATED_BLOCK = 128   # gated pipeline: the detector pass of block k + 1 runs (worker thread, own handle and stream) under the U-Net pass of
+                    # block k; rounded up to a whole number of the model's micro-batches so that no block ends in a ragged launch
+
+
+def gated_block(model) -> int:
+    c = max(1, int(getattr(model, "chunk", 32)))
+    return -(-GATED_BLOCK // c) * c
 
 
 def iter_frame_blocks(source, block: int = BLOCK):
@@ -125,14 +131,22 @@ def _detect_block(frames, detector) -> np.ndarray:
     return boxes
 
 
-def _blocks_with_boxes(frames, detector):
-    """``(block, boxes)`` pairs of the gated pipeline.  The detector network and the O(1)-per-frame temporal state machine of block
+def _blocks_with_boxes(frames, detector, model=None):
+    """``(block, boxes)`` pairs of the gated pipeline.  With the NATIVE detector backend (``detect_frames``: one batched device
+    pass per block, the GIL released inside the C-ABI) the detector network and the O(1)-per-frame temporal state machine of block
     k + 1 run on ONE worker thread (so blocks are detected in order: the state machine is sequential, detector.py:61-96) while the
-    caller segments block k; both calls release the GIL inside the C-ABI.  Nothing about the results changes: same boxes, in the same
-    order, as a detect-everything-first pass."""
+    caller segments block k.  Any other backend calls ``detector.detect`` per frame under the GIL -- a worker would overlap nothing --
+    and keeps the plain sequential pass over BLOCK-sized blocks.  Nothing about the results changes either way: same boxes, in the
+    same order, as a detect-everything-first pass.  (If the consumer abandons the generator, leaving the ``with`` block waits for
+    the detection in flight -- at most one block.)"""
     from concurrent.futures import ThreadPoolExecutor
 
-    it = (b for b in iter_frame_blocks(frames, GATED_BLOCK) if len(b))
+    if getattr(getattr(detector, "model", None), "detect_frames", None) is None:
+        for blk in iter_frame_blocks(frames, BLOCK):
+            if len(blk):
+                yield blk, _detect_block(blk, detector)
+        return
+    it = (b for b in iter_frame_blocks(frames, gated_block(model)) if len(b))
     with ThreadPoolExecutor(1) as pool:
         nxt = next(it, None)
         fut = pool.submit(_detect_block, nxt, detector) if nxt is not None else None
@@ -157,7 +171,7 @@ def area_waveform(frames, detector, model, device=None, threshold: float = 0.5) 
         detector.reset()
     out = []
     done = 0
-    pairs = _blocks_with_boxes(frames, detector) if detector is not None else ((b, None) for b in iter_frame_blocks(frames))
+    pairs = _blocks_with_boxes(frames, detector, model) if detector is not None else ((b, None) for b in iter_frame_blocks(frames))
     for blk, boxes in pairs:
         n = len(blk)
         if n == 0:

@@ -258,6 +258,12 @@ class UNet:
     def set_chunk(self, frames_per_launch: int) -> None:
         self._require()
         check(lib().og_unet_set_chunk(self._h, int(frames_per_launch)), "og_unet_set_chunk")
+        self._chunk = int(frames_per_launch)
+
+    @property
+    def chunk(self) -> int:
+        """Frames per kernel chain (micro-batch) the handle is set to (library default 32)."""
+        return getattr(self, "_chunk", 32)
 
     def set_graphs(self, enable: bool) -> None:
         self._require()

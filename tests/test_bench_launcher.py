@@ -46,6 +46,10 @@ def test_self_launch_weak_scaling_and_single_rank():
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["world"] == 3 and out["frames_per_step_all_gpus"] == 51 and out["scaling"] == "weak"
+    # an N > 1 run without --total-frames also carries config C4 (ONE 10 000-frame video, strong scaling, ragged last rank)
+    assert out["c4_strong"]["frames"] == 10000 and out["c4_strong"]["per_rank_frames"] == [3334, 3334, 3332] and out["c4_strong"]["waveform_ok"]
+    p = _run(["--gpus", "2", "--frames", "9", "--no-c4-strong"])
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["c4_strong"] is None
     p = _run(["--gpus", "1", "--frames", "5"])
     assert p.returncode == 0 and json.loads(p.stdout.strip())["world"] == 1
 

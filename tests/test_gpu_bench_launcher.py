@@ -33,7 +33,11 @@ def test_bench_starts_its_own_two_ranks_weak_scaling():
     assert out["config"]["frames_per_step_all_gpus"] == 256 and out["per_rank_frames"] == [128, 128]
     assert len(out["per_rank_fps"]) == 2 and all(v > 100 for v in out["per_rank_fps"])
     assert out["value"] > 1000 and out["host_inclusive"]["value"] > 1000 and out["host_inclusive"]["frames"] == 256
-    assert "roofline" not in out and "cpu_baseline" not in out          # N = 1 legs only
+    assert "roofline" not in out and "cpu_baseline" not in out and "gated_c3" not in out          # N = 1 legs only
+    # config C4 in the same line: one 10 000-frame video, contiguous shards, the all-gather inside the region, per-rank rates
+    c4 = out["c4_strong"]
+    assert c4["frames"] == 10000 and c4["per_rank_frames"] == [5000, 5000] and c4["scaling"] == "strong" and c4["collective"]["ranks"] == 2
+    assert c4["value"] > 1000 and len(c4["per_rank_fps"]) == 2 and all(v > 100 for v in c4["per_rank_fps"])
 
 
 def test_bench_strong_scaling_ragged_video_on_two_ranks():

@@ -1,10 +1,10 @@
 """GPU parity tests (-m gpu): HIP path through the C-ABI vs golden vectors and the CPU oracle.
 
 Tolerances
-  * layer tensors / logits: abs <= 5e-5 * max(1, |ref|max).  The reference is fp32 with a
+  * layer tensors / logits: abs <= BAND * max(1, |ref|max) (BAND = the reference's own noise, oracle.reference_band()).  The reference is fp32 with a
     backend-chosen summation order (oneDNN), so bit equality of floats is not defined even
     between two CPU runs; 2e-5 is the measured numpy-vs-reference noise on these vectors.
-  * masks / areas: bit-exact, except that a pixel may differ where |reference logit| <= 5e-5
+  * masks / areas: bit-exact, except that a pixel may differ where |reference logit| <= BAND
     (it sits on the decision boundary inside fp32 noise); every such flip is counted and the
     area may differ by at most that count.  The trained fixture has no such pixel: exact.
 """
@@ -20,7 +20,9 @@ from openglottal_amd.features import area_waveform, extract_features_unet
 
 pytestmark = pytest.mark.gpu
 
-TOL = 5e-5
+import oracle
+
+TOL = oracle.reference_band()   # the reference's own run-to-run logit difference (tests/golden/unet_full128_self_noise.npz: 3.475e-5)
 
 
 def unpack(bits, h=256, w=256):
@@ -207,7 +209,8 @@ def test_split_k_latency_mode(trained, full):
     m.set_option("splitk", 0)
     m.set_option("wino", 1)
     assert not np.array_equal(l0, l1)                                                 # the split path really ran
-    assert np.abs(l0 - l1).max() <= TOL
+    scale = max(1.0, float(np.abs(l0).max()))
+    assert np.abs(l0 - l1).max() <= 2 * TOL * scale      # two of OUR summation orders against each other: each within the band of the reference
     # fused reduce (last-arriving K part sums all parts in split order) == separate reduce kernel, bit for bit, every time
     mf.set_chunk(1)
     mf.set_option("splitk_fused", 0)
@@ -225,13 +228,13 @@ def test_split_k_latency_mode(trained, full):
         _, a_v, l_v = mf.segment(framesf, want_mask=False, want_logits=True)
         _, a_v2, l_v2 = mf.segment(framesf, want_mask=False, want_logits=True)
         assert np.array_equal(l_v, l_v2) and np.array_equal(a_v, a_v2)
-        assert np.abs(l_v - l0).max() <= TOL, (nt1, steps)
+        assert np.abs(l_v - l0).max() <= 2 * TOL * scale, (nt1, steps)
     mf.set_option("splitk_nt1", 1)
     mf.set_option("splitk_min_steps", 3)
     mf.set_chunk(32)
     mf.set_option("splitk", 0)
     mf.set_option("wino", 1)
-    assert np.abs(l1.reshape(8, -1)[:, gf["sample_idx"]] - gf["logits_samples"]).max() <= TOL
+    assert np.abs(l1.reshape(8, -1)[:, gf["sample_idx"]] - gf["logits_samples"]).max() <= TOL * max(1.0, float(np.abs(gf["logits_samples"]).max()))
     assert np.all(np.abs(a0.astype(int) - a1.astype(int)) <= ((l0 > 0) != (l1 > 0)).reshape(8, -1).sum(1))
 
 
