@@ -618,13 +618,15 @@ constexpr int conv_o_lds() {
            ((MODE == 0) ? 3 : 2) * 32 * NT * 128;
 }
 
-template <int NT, int MODE, int TH, int OCC>
+template <int NT, int MODE, int TH, int OCC, bool VS = false>
 int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     constexpr int PAD = (MODE == 0) ? 1 : 0;
     constexpr int lds = conv_o_lds<NT, MODE, TH>();
     static_assert(lds >= 4 * 5120, "the epilogue's per-wave scratch needs 20 KB");
     ConvArgs a = a_in;
     a.stamps = nullptr;  // the probe buffer is sized for the persistent kernel's grid; this kernel's timeline is tools/ubench/occ_timeline
+    if (VS) a.ksplit = 1;
+    else a.vsplit = 1;
     if (a.n_spatial * n_ntiles > kTileCounters) a.tile_counter = nullptr;
     if ((MODE == 2 || MODE == 3) && a.tile_counter == nullptr) a.ksplit = 1;   // these modes split K with the fused reduce only
     const int frames = a.n_spatial / (a.tiles_x * a.tiles_y);
@@ -644,7 +646,7 @@ int launch_conv_o(const LaunchCtx& c, const ConvArgs& a_in, int n_ntiles) {
     if (a.ksplit > 1)   // raw accumulators of every K part (4 waves x MS sub-tiles x 16 registers x 64 lanes), arrivals per tile
         plan_need((long long)a.n_spatial * n_ntiles * a.ksplit * 4 * (((TH / 2) / (4 / NT)) * 16 * 64) * 4,
                   a.tile_counter ? (long long)a.n_spatial * n_ntiles : 0);
-    OG_LAUNCH((k_conv_mfma_o<NT, MODE, TH, OCC>), dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), lds, c.stream, a);
+    OG_LAUNCH((k_conv_mfma_o<NT, MODE, TH, OCC, false, VS>), dim3(a.tiles_x, a.tiles_y, groups * G * a.zdiv), dim3(256), lds, c.stream, a);
     if constexpr (MODE == 0 || MODE == 1) {
         if (a.ksplit > 1 && a.tile_counter == nullptr) {
             OG_LAUNCH((k_splitk_epilogue<NT, MODE, TH>), dim3(a.n_spatial * n_ntiles), dim3(256), 4 * 5120, c.stream, a);
@@ -817,6 +819,12 @@ int init_kernel_attrs() {  // must not run inside a stream capture
     if ((rc = set_conv_p_attr<2, 1, 8, 1>())) return rc;
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                conv_o_lds<1, 0, 8>() + (12 * 20 + 352) * 4));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 0, 8, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 0, 8>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 0, 8, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 0, 8>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 2, 8, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 2, 8>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 2, 8, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 2, 8>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 3, 8, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 3, 8>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 3, 8, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 3, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 2, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 2, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<1, 2, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<1, 2, 8>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_conv_mfma_o<2, 3, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_o_lds<2, 3, 8>()));
@@ -947,6 +955,7 @@ int launch_conv(og_unet* h, const ConvLayer& L, int B, const Act& in, int in_off
         a.head_store_act = h->keep_taps;
     }
     a.ksplit = 1;
+    a.vsplit = 1;
     a.partial = h->d_partial;
     a.tile_counter = (h->splitk_fused && h->d_tile_counter) ? h->d_tile_counter : nullptr;
     if (h->precision == 1) {   // opt-in split precision: always the occupancy-shaped kernel, no split-K

@@ -177,6 +177,8 @@ struct ConvArgs {
     float zrcp;             // 1 / (zdiv << zgroup_shift)
     int zgroup_shift;       // log2 of the frames per z group
     int frames;             // B
+    int vsplit;             // k_conv_mfma_o<..., VS = true> only: > 1 = sum the K parts of a `vsplit`-way split IN REGISTERS, in split order
+                            // (bit-identical to ksplit = vsplit with the fused reduce): the detector's batched path (og_yolo.inc)
     int ksplit;             // >1: split-K.  Item = (tile, K-range); raw accumulators go to `partial`, and
     float* partial;         // k_splitk_epilogue sums them in split order and runs the epilogue (small-batch latency mode)
     int* tile_counter;      // k_conv_mfma_o split-K, fused reduce: arrivals per tile (zero between launches); nullptr = separate epilogue kernel
@@ -702,7 +704,12 @@ __device__ __forceinline__ int og_halo_swz(int py, int px) { return ((px >> 1) ^
 // Occupancy variant: ONE halo buffer (reloaded at each chunk boundary, the stall is covered by the
 // other workgroups) -> 39 KB of LDS, so 3-4 workgroups fit a CU instead of 2.  Same arithmetic and
 // accumulation order as k_conv_mfma.
-template <int NT, int MODE, int TH, int OCC, bool FIRST = false>
+// VS ("virtual split", the detector's batched launches): the workgroup runs the WHOLE K range but keeps the partial sums of an
+// a.vsplit-way split apart -- at every part boundary the running accumulators are folded into `vsum` and restart from zero, and the
+// epilogue sees vsum + last part -- i.e. exactly what the fused reduce of a real split (ksplit = vsplit) computes:
+// ((0 + p0) + p1) + ...  A frame's detector output then does not depend on whether its launch split K over workgroups (one-frame
+// latency path) or not (batched path).
+template <int NT, int MODE, int TH, int OCC, bool FIRST = false, bool VS = false>
 __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
     constexpr int TW = 16;
     constexpr int PAD = (MODE == 0 || MODE == 3) ? 1 : 0;                 // rows/columns of halo above / left of the tile
@@ -942,9 +949,34 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
 
     int step = s_lo;                             // absolute (chunk, tap) index: also the weight block's index
     const int step_end = s_hi;
+    // VS: part p of vs_n starts at unit (p * units) / vs_n, units = (chunk, tap) steps (MODE 0), chunks (MODE 1, 2), virtual chunks (MODE 3)
+    const int vs_n = VS ? a.vsplit : 1;
+    const int vs_units = a.n_chunks * TAPS_;
+    // (integer division runs on the vector ALU: readfirstlane brings the wave-uniform quotient back to a scalar, or the loop's
+    //  branches and the LDS-DMA's scalar operands would count as divergent)
+    int vp = 1, vnext = (VS && vs_n > 1) ? __builtin_amdgcn_readfirstlane(vs_units / vs_n) : -1;
+    f32x16 vsum[VS ? MS : 1];
+    if (VS) {
+#pragma unroll
+        for (int m = 0; m < MS; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vsum[m][r] = 0.f;
+    }
     for (int c = c_lo; c < c_hi; ++c) {
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
+            if (VS && ((MODE == 3) ? (t == 0 && c == vnext) : (c * TAPS_ + t == vnext))) {   // a part boundary: fold, restart from zero
+#pragma unroll
+                for (int m = 0; m < MS; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        vsum[m][r] += acc[m][r];
+                        acc[m][r] = 0.f;
+                    }
+                }
+                ++vp;
+                vnext = (vp < vs_n) ? __builtin_amdgcn_readfirstlane((vp * vs_units) / vs_n) : -1;
+            }
             if (MODE == 0 && ks_n > 1 && (c * TAPS + t < s_lo || c * TAPS + t >= s_hi)) continue;  // another K part's step
             if (MODE == 3) {  // tap (ty,tx) of the 2x2 kernel meets parity (py,px): zero unless (ty==1 || py==1) and (tx==1 || px==1)
                 const int par = c / cpc;
@@ -982,6 +1014,12 @@ __global__ __launch_bounds__(256, OCC) void k_conv_mfma_o(ConvArgs a) {
 
     if (st != nullptr && tid == 0) st[2] = __builtin_amdgcn_s_memtime();
     if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(3);
+    if (VS && vs_n > 1) {   // the fused reduce's last addition: (sum of the earlier parts) + the last part
+#pragma unroll
+        for (int m = 0; m < MS; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = vsum[m][r] + acc[m][r];
+    }
     // ---- epilogue (all staging buffers are dead behind the last barrier: LDS is scratch now) ----
     if (ks_n > 1) {
         // split-K: raw accumulators, register order, lane-contiguous (256-B stores); k_splitk_epilogue sums the parts

@@ -326,3 +326,49 @@ def test_latency_path_interleaved_with_batched_calls_and_no_detection(det):
     dev = torch.from_numpy(fr).to("cuda:0")
     for i in range(3):
         assert np.array_equal(d.detect_dev(dev[i], 1, 256, 256, 0.25)[0], one[i])
+
+
+def test_per_frame_and_batched_detector_are_bit_identical_on_2000_frames(det):
+    """the detector's arithmetic is a property of the handle.  `TemporalDetector.detect(frame)` (one frame per
+    call: K parts on separate workgroups, fused reduce) and `detect_frames(video)[i]` (batched: the same parts summed in registers,
+    k_conv_mfma_o<..., VS>) return the same five floats BIT FOR BIT on 2 000 seeded frames -- so the truncations of
+    openglottal/models/detector.py:68-69 (`int(x2 - x1)`) and :94-95 (`int(np.clip(...))`) see the same numbers, the integer boxes
+    after `update()` are equal, and the gated areas of the per-frame loop equal the streamed ones (features.py:240-245)."""
+    import openglottal_amd as og
+    from openglottal_amd.features import area_waveform
+    from openglottal_amd.utils import bgr_to_gray, normalize_box, unet_segment_frame
+
+    sd, d = det
+    n = 2000
+    fr = np.stack([synth.bench_frame_bgr(i) for i in range(n)])
+    fr[::7] = frames(len(fr[::7]), 256, 256, seed=5)              # every 7th frame structured: other boxes than the noise frames'
+    batched = d.detect_frames(fr, 0.25)
+    per_frame = np.stack([d.detect_frames(fr[i:i + 1], 0.25)[0] for i in range(n)])
+    assert np.array_equal(batched, per_frame), int((batched != per_frame).any(axis=1).sum())
+    assert int((batched[:, 4] >= 0).sum()) >= n // 2                      # the comparison is about real boxes
+    for lb in (0, 4):                                                       # another scheduling of the same sums
+        d.set_option("latency_batch", lb)
+        try:
+            assert np.array_equal(d.detect_frames(fr[:64], 0.25), batched[:64])
+            assert np.array_equal(np.stack([d.detect_frames(fr[i:i + 3], 0.25) for i in range(0, 63, 3)]).reshape(-1, 5), batched[:63])
+        finally:
+            d.set_option("latency_batch", 1)
+    ta, tb = og.TemporalDetector(d, conf=0.25), og.TemporalDetector(d, conf=0.25)
+    boxes_a = [ta.detect(f) for f in fr]                                    # the reference's call, frame by frame
+    boxes_b = [tb.update(batched[i:i + 1, :4], batched[i:i + 1, 4], 256, 256) if batched[i, 4] >= 0 else tb.update(None, None, 256, 256) for i in range(n)]
+    assert boxes_a == boxes_b
+    feats = (32, 64, 128, 256)
+    m = og.UNet(1, 1, feats)
+    m.load_state_dict(synth.make_unet_state_dict(feats, seed=20260227, head_scale=3.4732823371887207, head_bias=-2.890756130218506))
+    m.to("cuda:0").eval()
+    m.set_chunk(64)
+    streamed = area_waveform(fr, og.TemporalDetector(d, conf=0.25), m)
+    tc = og.TemporalDetector(d, conf=0.25)
+    loop = np.zeros(n)
+    for i, f in enumerate(fr):                                              # features.py:234-245, one call each per frame
+        mask = unet_segment_frame(bgr_to_gray(f), m, "cuda:0")
+        box = tc.detect(f)
+        if box is not None:
+            x1, y1, x2, y2 = normalize_box(box, 256, 256)
+            loop[i] = float(np.sum(mask[y1:y2, x1:x2] > 0))
+    assert np.array_equal(loop, streamed), int((loop != streamed).sum())
