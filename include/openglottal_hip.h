@@ -13,7 +13,14 @@
  *
  * Conventions
  *  - every call returns 0 on success or a negative OG_E* code; nothing throws
- *    or aborts across the ABI; og_last_error() returns a thread-local string.
+ *    across the ABI; og_last_error() returns a thread-local string.  Every kernel
+ *    launch reports its own failure (OG_EHIP from the call that issued it) and every
+ *    launch's grid / LDS / workspace / counter bounds are decided on the host before
+ *    anything runs (og_unet_plan() walks those decisions without a device).  What the
+ *    library cannot turn into a code: a GPU memory fault -- the HIP runtime answers
+ *    it with abort() in the process.  A call that fails half-way leaves the handle
+ *    usable (arrival counters restored on every error path).
+ *  - the calling thread's current HIP device is restored on every exit path.
  *  - host buffers are caller-owned and only read/written during the call.
  *  - *_dev entry points take DEVICE pointers (hipMalloc'd or a torch tensor's
  *    data_ptr()), enqueue on the handle's stream and return without syncing;
@@ -109,6 +116,12 @@ int og_unet_segment_u8_dev(og_unet* h, const uint8_t* gray_dev, int B, int H, in
  * boxes only become known after the sequential TemporalDetector pass). */
 int og_mask_area_dev(og_unet* h, const uint8_t* mask_dev, int B, int H, int W, const int32_t* boxes_dev, int32_t* area_dev);
 
+/* `cv2.cvtColor(frm_bgr, cv2.COLOR_BGR2GRAY)` (openglottal/features.py:235) on the HOST, for callers that keep the reference's
+ * per-frame loop (one gray frame per `unet_segment_frame` call): n_pixels BGR triples -> n_pixels gray bytes, OpenCV's published u8
+ * path (15-bit fixed point, R 9798 / G 19235 / B 3735, (x + 2^14) >> 15) -- the arithmetic of k_bgr2gray.  No device involved.
+ * PARITY UNPINNED against OpenCV (absent from the reference's snapshot and from the build image). */
+int og_bgr2gray_host(const uint8_t* bgr, long long n_pixels, uint8_t* gray);
+
 /* = cv2.cvtColor(frame, COLOR_BGR2GRAY) (features.py:235) for [B,H,W,3] u8 on the device. */
 int og_bgr2gray_dev(og_unet* h, const uint8_t* bgr_dev, int B, int H, int W, uint8_t* gray_dev);
 
@@ -163,8 +176,16 @@ int og_unet_set_graphs(og_unet* h, int enable);
  * (its target workgroups per CU / split when the launch fills less than 1/div of them),
  * "occ_min_pct" 0..400 (occupancy kernel when a launch has at least that many workgroups per 100 CUs), "convt_occ" 0|1, "fuse_first" 0|1 (first layer computed inside downs.0's second conv), "fuse_head" 0|1 (head +
  * threshold + area inside the last conv's epilogue), "keep_taps" 0|1, "precision" 0|1 (NOT bit-identical: 0 = exact f32, the default and the parity reference; 1 = opt-in split precision -- activations and weights as f16 hi/lo pairs, three v_mfma_f32_32x32x16_f16 per f32 product, f32 accumulation; passes the reference fixtures at the f32 tolerance, 2.5x faster; an activation beyond the f16 range makes the call fail with OG_ERANGE), "h_square" 0|1 (its wave tiling), "stream" 0|1 (og_unet_segment_u8 through the streaming engine, default 1; 0 = whole batch staged at once), "dual" 0|1 (micro-batches of one call alternate over extra lanes = streams/arenas, so that launch tails overlap) with "lanes" 0..3 (0 = 3 lanes up to 16 frames per launch, else 2), and
- * "wino_ps" 0..4 [1] (Winograd launches that fill less than a quarter of the CUs spread a tile's 16 positions over 16 / PN workgroups,
- * k_conv_wino_ps: the same sums, bit for bit; 0 off, 1 auto, 2 / 3 / 4 force PN = 4 / 2 / 1).
+ * "wino_w" 0..4 [1] (under-filled Winograd launches -- one frame per kernel chain, the reference's call pattern utils.py:235-237 --
+ * on finer tiles with the 16 positions split over the four WAVES of a workgroup, V transformed in registers, accumulators exchanged
+ * through LDS (k_conv_wino_w), deep layers with a tile's four position rows on four workgroups (k_conv_wino_wp); the same sums as
+ * k_conv_wino, bit for bit; 0 off, 1 auto -- by tiles, channels and the number of lanes in flight --, 2 / 3 force k_conv_wino_w with
+ * one / two 32-window blocks per workgroup, 4 forces k_conv_wino_wp), "convt_w" 0|1 [1] (under-filled transposed convs on
+ * 32-pixel x 32-column wave tiles, k_convt_w: bit-identical),
+ * "wino_ps" 0..4 [1] (round 3's form of the same, used when "wino_w" is 0: a tile's 16 positions over 16 / PN workgroups,
+ * k_conv_wino_ps: the same sums, bit for bit; 0 off, 1 auto, 2 / 3 / 4 force PN = 4 / 2 / 1),
+ * "inject_fault" n (TEST HOOK: the n-th conv launch from now on fails with OG_EHIP after scribbling over the arrival counters of the
+ * fused reduces; every error path restores them -- tests/test_gpu_recovery.py).
  *
  * The two options that DO change the arithmetic:
  * "wino" 0|1 [1]: the form of the HANDLE.  1 = every 3x3 conv whose map tiles (H, W multiples of 16; 32 rows for 32-column layers)
@@ -234,10 +255,14 @@ og_yolo* og_yolo_create(int nc);                      /* nc: number of classes (
 void og_yolo_destroy(og_yolo* h);
 int og_yolo_set_tensor(og_yolo* h, const char* key, const void* host, const int64_t* shape, int ndim, int dtype);
 int og_yolo_finalize(og_yolo* h);
-/* Tuning knobs (defaults in brackets).  "latency_batch" [1]: calls of at most this many frames (the reference's
- * one-frame-per-call pattern, detector.py:58) take the latency path -- convs that would leave most of the chip idle split
- * K over workgroups, so their float sums are ordered differently from the batched path (results agree to rounding; 0 turns
- * the path off and makes every call bit-identical to the batched one).  "splitk_slots" [1], "splitk_div" [2]: as og_unet's. */
+/* Tuning knobs (defaults in brackets).  The detector's arithmetic is a property of the HANDLE (round 4): a conv whose one-frame
+ * launch would leave most of the chip idle sums its K range as `ks` parts combined in split order -- ks decided from the layer, the
+ * frame size and these options, never from B.  "latency_batch" [1]: calls of at most this many frames (the reference's
+ * one-frame-per-call pattern, detector.py:58) run the parts on separate workgroups with a fused reduce (the latency path); larger
+ * calls run them in one workgroup and keep them apart in registers -- THE SAME BITS, so `detect(frame)` and `detect_frames(video)[i]`
+ * return the same five floats and detector.py:68-69,94-95 truncate the same numbers (0: every call takes the batched kernels).
+ * "splitk_max" [8], "splitk_min_steps" [3], "splitk_slots" [1], "splitk_div" [2], "latency_nt1" [1] shape the split (they change the
+ * summation order, for every call of the handle alike); "head_fused" [1]: a Detect level's box and class branches as one chain. */
 int og_yolo_set_option(og_yolo* h, const char* name, int value);
 int og_yolo_num_anchors(og_yolo* h, int H, int W);    /* (H/8)(W/8)+(H/16)(W/16)+(H/32)(W/32) */
 /* frames [B,H,W,3] u8 BGR at network resolution (H,W multiples of 32; the caller letterboxes).

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "og_mask_stats_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "og_mask_area_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "og_bgr2gray_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "og_bgr2gray_host": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p]),
     "og_unet_sync": (C.c_int, [C.c_void_p]),
     "og_unet_stream": (C.c_void_p, [C.c_void_p]),
     "og_unet_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),

@@ -1531,6 +1531,15 @@ inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 
 }  // namespace
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// k_bgr2gray's arithmetic on the host: OpenCV's published u8 path (15-bit fixed point); an AVX2 clone is picked at load time
+__attribute__((target_clones("avx2", "default")))
+#endif
+static void bgr2gray_host_loop(const uint8_t* __restrict__ bgr, long long n, uint8_t* __restrict__ gray) {
+    for (long long i = 0; i < n; ++i)
+        gray[i] = (uint8_t)((bgr[3 * i] * 3735 + bgr[3 * i + 1] * 19235 + bgr[3 * i + 2] * 9798 + (1 << 14)) >> 15);
+}
+
 #include "og_yolo.inc"
 
 extern "C" {
@@ -2162,6 +2171,12 @@ int og_mask_area_dev(og_unet* h, const uint8_t* mask, int B, int H, int W, const
     const int HW = H * W, bpf = (HW + 4095) / 4096;
     hipLaunchKernelGGL(k_mask_area, dim3(B * bpf), dim3(256), 0, h->stream, mask, HW, W, boxes, area, bpf);
     HIPCHK(hipGetLastError());
+    return OG_OK;
+}
+
+int og_bgr2gray_host(const uint8_t* bgr, long long n_pixels, uint8_t* gray) {
+    if (n_pixels < 0 || (n_pixels > 0 && (!bgr || !gray))) return fail(OG_EINVAL, "bad argument");
+    bgr2gray_host_loop(bgr, n_pixels, gray);
     return OG_OK;
 }
 

@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from ._lib import OpenGlottalHipError
+from ._lib import OpenGlottalHipError, check, lib, ptr
 
 NET_SIZE = 256  # unet_segment_frame resizes every frame to 256x256 (utils.py:234)
 
@@ -19,9 +19,20 @@ def bgr_to_gray(frame_bgr: np.ndarray) -> np.ndarray:
     """
     f = np.asarray(frame_bgr)
     if f.ndim >= 3 and f.shape[-1] == 3:
-        b, g, r = (f[..., i].astype(np.int32) for i in range(3))
-        return ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8)
+        if f.dtype == np.uint8 and f.flags.c_contiguous:
+            # the per-frame loop calls this once per frame (features.py:235): one pass in the C library (og_bgr2gray_host, host only)
+            # instead of eight numpy passes -- the same integers (bgr_to_gray_numpy, tests/test_host_logic.py)
+            out = np.empty(f.shape[:-1], np.uint8)
+            check(lib().og_bgr2gray_host(ptr(f), int(out.size), ptr(out)), "og_bgr2gray_host")
+            return out
+        return bgr_to_gray_numpy(f)
     return f.astype(np.uint8)
+
+
+def bgr_to_gray_numpy(f: np.ndarray) -> np.ndarray:
+    """The same arithmetic in numpy (any integer dtype / memory layout; the check of the C loop)."""
+    b, g, r = (np.asarray(f)[..., i].astype(np.int32) for i in range(3))
+    return ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8)
 
 
 def unet_segment_frame(frame_gray: np.ndarray, model, device=None, threshold: float = 0.5) -> np.ndarray:

@@ -159,3 +159,24 @@ def test_load_frames_from_npy_and_png_directory(tmp_path):
     seq = load_frames_bgr(str(d))
     assert len(seq) == 4 and all(np.array_equal(seq[i], vid[i]) for i in range(3)) and seq[3].ndim == 2
     assert load_frames_bgr(str(tmp_path / "missing.avi")) == []
+
+
+def test_host_bgr_to_gray_in_the_c_library_equals_the_numpy_restatement():
+    """`og_bgr2gray_host` (the per-frame loop's cv2.cvtColor, features.py:235) against the numpy restatement of OpenCV's u8 path:
+    every value of one channel against extremes of the others, random frames, odd sizes, R = G = B exact, non-contiguous input."""
+    from openglottal_amd.utils import bgr_to_gray, bgr_to_gray_numpy
+
+    rs = np.random.RandomState(3)
+    for shape in [(256, 256, 3), (1, 1, 3), (37, 5, 3), (4, 256, 256, 3)]:
+        f = rs.randint(0, 256, shape).astype(np.uint8)
+        assert np.array_equal(bgr_to_gray(f), bgr_to_gray_numpy(f))
+    v = np.arange(256, dtype=np.uint8)
+    for c in range(3):
+        for lo in (0, 255):
+            f = np.full((256, 1, 3), lo, np.uint8)
+            f[:, 0, c] = v
+            assert np.array_equal(bgr_to_gray(f), bgr_to_gray_numpy(f))
+    g = np.repeat(v[:, None, None], 3, axis=2)
+    assert np.array_equal(bgr_to_gray(g)[:, 0], v)               # (v, v, v) -> v
+    nc = rs.randint(0, 256, (64, 64, 6)).astype(np.uint8)[..., ::2]     # a strided view takes the numpy path: same integers
+    assert not nc.flags.c_contiguous and np.array_equal(bgr_to_gray(nc), bgr_to_gray_numpy(nc))
