@@ -1775,10 +1775,11 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w(ConvArgs a) {
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) glds16b((unsigned)lane * 16u, ws, (unsigned)((c * 16 + 4 * wave + cc) * 1024), base + cc * 1024);
     };
+    // only what the first chunk needs is requested up front (raw(0), U(0), U(1): 14 / 19 pieces); the rest of the look-ahead --
+    // U(2 .. UD), raw(1) -- is issued behind the MFMAs of chunk 0 (MODE 3 below), in the order the counted waits assume
     issue_raw(0);
-#pragma unroll
-    for (int c = 0; c <= UD; ++c) issue_u(c);
-    issue_raw(1);
+    issue_u(0);
+    issue_u(1);
 
     // position row of this wave: B^T row i = x[ra] (+ if i == 1, else -) x[rb]
     const int ra = (wave == 0) ? 0 : (wave == 2) ? 2 : 1;
@@ -1835,7 +1836,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w(ConvArgs a) {
     // workgroup barrier WITHOUT a fence: __syncthreads() would make hipcc wait vmcnt(0) for the loads it tracks (scale / shift), i.e.
     // for every LDS-DMA queued behind them; hipcc's own LDS reads are waited for here, the DMA by the counted vmcnt in front
     auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * UD + RAW_IT) : "memory");   // raw(0) and U(0) landed; U(1..UD), raw(1) in flight
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // raw(0) and U(0) landed; U(1) in flight
     barrier();
 #pragma unroll
     for (int r = 0; r < NR; ++r) read_raw(r, 0);
@@ -1851,7 +1852,8 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w(ConvArgs a) {
     // fill the matrix pipe's shadow, so the side work of the NEXT chunk (c_rd = 4 s_rd + j_rd) is cut into micro-ops with a fixed
     // slot behind the MFMAs (as k_conv_wino does): slot 0 the waits (+ the stage barrier), then 2 LDS reads per slot, the 4 U pieces
     // of chunk c_rd + UD one per slot, the transform one quad-op per slot, and on a stage boundary (MODE 2) the raw pieces of stage
-    // s_rd + 1 one per slot.  MODE 0: last chunk, MFMAs only.
+    // s_rd + 1 one per slot.  MODE 0: last chunk, MFMAs only.  MODE 3: chunk 0 -- it also issues the look-ahead the prologue left
+    // out, U(2 .. UD) then raw(1), in front of its own U(UD + 1), spread over its slots.
     constexpr int S_DU = NR / 2 + 2, S_X = NR / 2 + 3, S_DR = NR / 2 + 6;
     static_assert(S_X + 8 * WB <= 16 * WB && S_DR + RAW_IT <= 16 * WB, "side work of a chunk must fit its MFMA slots");
     auto chunk = [&](int cur, int mode, int s_rd, int j_rd, int c_rd) {
@@ -1873,8 +1875,33 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w(ConvArgs a) {
                     const float av = tv[cur][wb][cc][e], bw = bv[cur][cc][e];
                     acc[wb][cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw, acc[wb][cc], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
+                    if (mode == 3 && n >= 1) {   // pieces [p0, p1) of: U(2 .. UD) | raw(1) | U(UD + 1)
+                        constexpr int NP = 4 * UD + RAW_IT, NSL = 16 * WB - 1;
+                        const int p0 = ((n - 1) * NP) / NSL, p1 = (n * NP) / NSL;
+#pragma unroll
+                        for (int pp = 0; pp < 3; ++pp) {
+                            const int q = p0 + pp;
+                            if (q < p1) {
+                                if (q < 4 * (UD - 1) || q >= 4 * (UD - 1) + RAW_IT) {
+                                    const int qu = (q < 4 * (UD - 1)) ? q : q - RAW_IT;      // piece index among the U pieces of chunks 2 .. UD + 1
+                                    const int cq = 2 + qu / 4, pc_ = qu % 4;
+                                    og_i32x4 wq = w_rsrc;
+                                    wq.z = (cq < n_ck) ? w_rsrc.z : 0;
+                                    const unsigned bq = __builtin_amdgcn_readfirstlane(lds0 + UBASE + (unsigned)((cq % US) * UCH) + wave * 4096);
+                                    glds16b((unsigned)lane * 16u, wq, (unsigned)((cq * 16 + 4 * wave + pc_) * 1024), bq + pc_ * 1024);
+                                } else {
+                                    const int it = q - 4 * (UD - 1);
+                                    og_i32x4 rq = in_rsrc;
+                                    rq.z = (1 < n_st) ? in_rsrc.z : 0;
+                                    const unsigned bq = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)RAW_PAD + wave * 1024);
+                                    glds16b(hoff[it], rq, 128u, bq + it * 4096);
+                                }
+                            }
+                        }
+                    }
                     if (mode != 0) {
                         if (n == 0) {
+                            if (mode == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // U(1): nothing younger has been issued yet
                             if (mode == 2) {
                                 // the next chunk opens stage s_rd: its raw halo (issued 4 chunks = 12 younger U pieces ago) has landed
                                 // for every wave behind this barrier, and every read of stage s_rd - 1 (taken a chunk ago) has
@@ -1884,7 +1911,8 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w(ConvArgs a) {
                             }
                             // U(c_rd): younger than it are U(c_rd + 1 .. c_rd + UD - 1) and the raw stage issued in the UD chunks
                             // before this one, if any
-                            if (UD == 4 || mode != 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (UD - 1) + RAW_IT) : "memory");
+                            if (mode == 3) {
+                            } else if (UD == 4 || mode != 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (UD - 1) + RAW_IT) : "memory");
                             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (UD - 1)) : "memory");
                             if (mode == 2) {
                                 const unsigned ring = (unsigned)((s_rd & 1) * RAW_PAD);
@@ -1900,22 +1928,28 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w(ConvArgs a) {
                             bv[cur ^ 1][c0] = og_lds_read16(ucur + (unsigned)(c0 * 1024));
                             bv[cur ^ 1][c0 + 1] = og_lds_read16(ucur + (unsigned)((c0 + 1) * 1024));
                         }
-                        if (n >= S_DU && n < S_DU + 4) glds16b((unsigned)lane * 16u, ws, us + (unsigned)((n - S_DU) * 1024), ub + (n - S_DU) * 1024);
+                        if (mode != 3 && n >= S_DU && n < S_DU + 4) glds16b((unsigned)lane * 16u, ws, us + (unsigned)((n - S_DU) * 1024), ub + (n - S_DU) * 1024);
                         if (n >= S_X && n < S_X + 8 * WB) xf((n - S_X) >> 3, (n - S_X) & 7, cur ^ 1);
                         if (mode == 2 && n >= S_DR && n < S_DR + RAW_IT) glds16b(hoff[n - S_DR], rs, (unsigned)(s_rd + 1) * 128u, rbs + (n - S_DR) * 4096);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
     };
-    // (the last stage is peeled: a branch inside the loop made hipcc keep two copies of the accumulators and move all 64 WB
-    //  registers there and back once per stage)
-    for (int s = 0; s + 1 < n_st; ++s) {
+    // (straight-line stages: a branch around a chunk inside the loop made hipcc keep two copies of the accumulators and move all
+    //  64 WB registers there and back once per stage)
+    chunk(0, 3, 0, 1, 1);                                                        // chunk 0: also the rest of the look-ahead
+    chunk(1, 1, 0, 2, 2);
+    chunk(0, 1, 0, 3, 3);
+    if (n_st > 1) {
+        chunk(1, 2, 1, 0, 4);                                                    // chunk 3 before stage 1
+        for (int s = 1; s + 1 < n_st; ++s) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) chunk(j & 1, 1, s, j + 1, 4 * s + j + 1);   // chunks 4 s + j, j < 3: the next chunk is in the same stage
-        chunk(1, 2, s + 1, 0, 4 * s + 4);                                        // chunk 4 s + 3 before another stage
+            for (int j = 0; j < 3; ++j) chunk(j & 1, 1, s, j + 1, 4 * s + j + 1);   // chunks 4 s + j, j < 3: the next chunk is in the same stage
+            chunk(1, 2, s + 1, 0, 4 * s + 4);                                    // chunk 4 s + 3 before another stage
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) chunk(j & 1, 1, n_st - 1, j + 1, 4 * (n_st - 1) + j + 1);
     }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) chunk(j & 1, 1, n_st - 1, j + 1, 4 * (n_st - 1) + j + 1);
     chunk(1, 0, 0, 0, 0);                                                        // the last chunk: MFMAs only
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the out-of-range tail pieces still write (zeros) into the rings
     barrier();
