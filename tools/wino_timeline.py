@@ -8,8 +8,11 @@ import openglottal_amd as og
 from openglottal_amd import synth
 from openglottal_amd._lib import lib, ptr, check
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+OPTS = [a.split("=") for a in sys.argv[2:]]
 feats = (32, 64, 128, 256)
 m = og.UNet(1, 1, feats); m.load_state_dict(synth.make_unet_state_dict(feats, seed=20260227, head_scale=3.47, head_bias=-2.89)); m.to("cuda:0").eval()
+for k, v in OPTS:
+    m.set_option(k, int(v))
 fr = torch.from_numpy(synth.bulk_gray_frames(B)).cuda()
 prof = m.profile(fr, B, 256, 256, reps=2)
 m.clock_probe(fr, B, 256, 256)
