@@ -11,4 +11,4 @@ mkdir -p build
 "$HIPCC" --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -fsanitize=address -fno-gpu-sanitize -shared-libasan -Wno-unused-function \
     -o build/libopenglottal_hip_asan.so openglottal_amd/csrc/og_api.hip
 OPENGLOTTAL_HIP_LIB="$PWD/build/libopenglottal_hip_asan.so" LD_PRELOAD="$RT" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:abort_on_error=1 \
-    python3 -m pytest tests/test_abi_errors.py tests/test_host_logic.py -q -p no:cacheprovider
+    python3 -m pytest tests/test_abi_errors.py tests/test_host_logic.py tests/test_launch_plan.py -q -p no:cacheprovider
