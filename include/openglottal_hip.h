@@ -184,6 +184,10 @@ int og_unet_set_graphs(og_unet* h, int enable);
  * 32-pixel x 32-column wave tiles, k_convt_w: bit-identical),
  * "wino_ps" 0..4 [1] (round 3's form of the same, used when "wino_w" is 0: a tile's 16 positions over 16 / PN workgroups,
  * k_conv_wino_ps: the same sums, bit for bit; 0 off, 1 auto, 2 / 3 / 4 force PN = 4 / 2 / 1),
+ * "zero_copy" 0|1 [1] (host entry points, calls of ONE micro-batch of at most 4 frames -- the reference's per-frame call,
+ * utils.py:235-237: the first kernel reads the frame from, and the last ones write the mask / area to, the engine's pinned host
+ * buffers directly instead of through H2D / D2H / memset commands, each of which costs a ~5 us launch floor on the one stream:
+ * 0.370 -> 0.358 ms per unet_segment_frame; results identical),
  * "inject_fault" n (TEST HOOK: the n-th conv launch from now on fails with OG_EHIP after scribbling over the arrival counters of the
  * fused reduces; every error path restores them -- tests/test_gpu_recovery.py).
  *
@@ -262,7 +266,9 @@ int og_yolo_finalize(og_yolo* h);
  * calls run them in one workgroup and keep them apart in registers -- THE SAME BITS, so `detect(frame)` and `detect_frames(video)[i]`
  * return the same five floats and detector.py:68-69,94-95 truncate the same numbers (0: every call takes the batched kernels).
  * "splitk_max" [8], "splitk_min_steps" [3], "splitk_slots" [1], "splitk_div" [2], "latency_nt1" [1] shape the split (they change the
- * summation order, for every call of the handle alike); "head_fused" [1]: a Detect level's box and class branches as one chain. */
+ * summation order, for every call of the handle alike); "head_fused" [1]: a Detect level's box and class branches as one chain;
+ * "zero_copy" [1]: latency-path calls without `pred` read the frame from, and write `best` to, the handle's pinned host buffer directly
+ * (no H2D / D2H command on the 58-launch chain's one stream). */
 int og_yolo_set_option(og_yolo* h, const char* name, int value);
 int og_yolo_num_anchors(og_yolo* h, int H, int W);    /* (H/8)(W/8)+(H/16)(W/16)+(H/32)(W/32) */
 /* frames [B,H,W,3] u8 BGR at network resolution (H,W multiples of 32; the caller letterboxes).

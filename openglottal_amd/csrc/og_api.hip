@@ -185,6 +185,7 @@ struct og_unet {
                          // Which layers take it is a function of the handle's options and of (H, W) alone -- never of the micro-batch
                          // size, the lane, the shard or the entry point -- so a frame's mask is a function of the frame only
                          // (features.py:234-238 has no cross-frame state either).  0: the direct kernels for every layer.
+    int zero_copy = 1;   // per-frame calls: the chain reads / writes the pinned host buffers directly (see fill() in stream_impl)
     int wino_ps = 1;     // under-filled Winograd launches spread a tile's 16 positions over several workgroups (k_conv_wino_ps: bit-identical);
                          // 0 off, 1 auto, 2 / 3 / 4 force PN = 4 / 2 / 1 on every launch that qualifies
     int wino_w = 1;      // under-filled Winograd launches on k_conv_wino_w (the 16 positions over the four waves of a workgroup, finer
@@ -1875,6 +1876,7 @@ int og_unet_set_option(og_unet* h, const char* name, int value) {
     else if (n == "wino" && (value == 0 || value == 1)) slot = &h->wino;
     else if (n == "wino_first" && (value == 0 || value == 1)) slot = &h->wino_first;
     else if (n == "wino_ps" && value >= 0 && value <= 4) slot = &h->wino_ps;
+    else if (n == "zero_copy" && (value == 0 || value == 1)) slot = &h->zero_copy;
     else if (n == "wino_w" && value >= 0 && value <= 4) slot = &h->wino_w;
     else if (n == "inject_fault" && value >= 0 && value <= 1000) slot = &h->inject_fault;
     else if (n == "splitk_fused" && (value == 0 || value == 1)) slot = &h->splitk_fused;
@@ -2034,26 +2036,46 @@ static int stream_impl(og_unet* h, const uint8_t* frames, const uint8_t* const* 
         // a call that is ONE micro-batch has nothing to overlap: its copies go on the compute stream, in order, and the two
         // cross-stream hand-overs (tens of microseconds each on a one-frame call) disappear
         const hipStream_t s_in = single ? lane->stream : R.s_h2d, s_out = single ? lane->stream : R.s_d2h;
+        // The per-frame call (utils.py:235-237: one frame in, one mask out): every copy command costs a launch floor (~5 us) on the
+        // one stream there is, more than moving 64 KB costs.  So the kernels read the frame from, and write the mask / area to, the
+        // slot's PINNED host buffers directly (mapped into the device's address space; the writes are visible to the host once the
+        // completion event has fired): no H2D, no D2H, no memset command.
+        const bool zc = single && nb <= 4 && h->zero_copy && !logits && (src == s.h_in || pinned);
+        uint8_t* z_in = nullptr; uint8_t* z_mask = nullptr; int32_t* z_area = nullptr; int32_t* z_boxes = nullptr;
+        if (zc) {
+            HIPCHK(hipHostGetDevicePointer((void**)&z_in, (void*)src, 0));
+            if (mask) HIPCHK(hipHostGetDevicePointer((void**)&z_mask, s.h_mask, 0));
+            if (area) { HIPCHK(hipHostGetDevicePointer((void**)&z_area, s.h_area, 0)); memset(s.h_area, 0, (size_t)nb * 4); }
+            if (boxes) { memcpy(s.h_boxes, boxes + 4 * (size_t)b0, (size_t)nb * 16); HIPCHK(hipHostGetDevicePointer((void**)&z_boxes, s.h_boxes, 0)); }
+        } else {
         HIPCHK(hipMemcpyAsync(s.d_in, src, nb * fb, hipMemcpyHostToDevice, s_in));
         if (boxes) {
             memcpy(s.h_boxes, boxes + 4 * (size_t)b0, (size_t)nb * 16);
             HIPCHK(hipMemcpyAsync(s.d_boxes, s.h_boxes, (size_t)nb * 16, hipMemcpyHostToDevice, s_in));
         }
+        }
         if (!single) {
             HIPCHK(hipEventRecord(s.ev_h2d, R.s_h2d));
             HIPCHK(hipStreamWaitEvent(lane->stream, s.ev_h2d, 0));
         }
-        const uint8_t* gray = s.d_in;
+        const uint8_t* gray = zc ? z_in : s.d_in;
         if (ch == 3) {   // cv2.cvtColor(frm_bgr, COLOR_BGR2GRAY) of features.py:235, on the device, in front of the chain
             const long long n = (long long)nb * H * W;
-            hipLaunchKernelGGL(k_bgr2gray, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, s.d_in, s.d_gray, n);
+            hipLaunchKernelGGL(k_bgr2gray, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, gray, s.d_gray, n);
             HIPCHK(hipGetLastError());
             gray = s.d_gray;
         }
-        if (area) HIPCHK(hipMemsetAsync(s.d_area, 0, (size_t)nb * 4, lane->stream));
-        int rc2 = run_chunk(lane, KIND_U8, gray, nb, H, W, thr, boxes ? s.d_boxes : nullptr, mask ? s.d_mask : nullptr,
-                            area ? s.d_area : nullptr, logits ? s.d_logits : nullptr);
+        if (area && !zc) HIPCHK(hipMemsetAsync(s.d_area, 0, (size_t)nb * 4, lane->stream));
+        int rc2 = zc ? run_chunk(lane, KIND_U8, gray, nb, H, W, thr, z_boxes, z_mask, z_area, nullptr)
+                     : run_chunk(lane, KIND_U8, gray, nb, H, W, thr, boxes ? s.d_boxes : nullptr, mask ? s.d_mask : nullptr,
+                                 area ? s.d_area : nullptr, logits ? s.d_logits : nullptr);
         if (rc2) return rc2;
+        if (zc) {
+            HIPCHK(hipEventRecord(s.ev_out, s_out));
+            s.b0 = b0;
+            s.nb = nb;
+            return OG_OK;
+        }
         if (!single) {
             HIPCHK(hipEventRecord(s.ev_done, lane->stream));
             HIPCHK(hipStreamWaitEvent(R.s_d2h, s.ev_done, 0));

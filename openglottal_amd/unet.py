@@ -112,11 +112,13 @@ class UNet:
     forward = __call__
 
     # ── batched fast path (what extract_features_unet / bench use) ──────────
-    def segment(self, gray, threshold: float = 0.5, boxes=None, want_mask: bool = True, want_logits: bool = False):
+    def segment(self, gray, threshold: float = 0.5, boxes=None, want_mask: bool = True, want_logits: bool = False,
+                want_area: bool = True):
         """`unet_segment_frame` + area count for host frames ``[B,H,W]`` u8.
 
-        Returns ``(mask u8 {0,255} | None, area int32 [B], logits f32 | None)``.
+        Returns ``(mask u8 {0,255} | None, area int32 [B] | None, logits f32 | None)``.
         ``boxes``: int32 ``[B,4]`` (x1,y1,x2,y2), ``x1 < 0`` ⇒ no detection ⇒ area 0.
+        ``want_area=False`` (the mask-only call of utils.py:218-241) spares the count reduction's launch.
         """
         self._require()
         g = np.ascontiguousarray(gray, dtype=np.uint8)
@@ -124,7 +126,7 @@ class UNet:
             g = g[None]
         B, H, W = g.shape
         mask = np.empty((B, H, W), np.uint8) if want_mask else None
-        area = np.zeros(B, np.int32)
+        area = np.zeros(B, np.int32) if want_area else None
         logits = np.empty((B, H, W), np.float32) if want_logits else None
         bx = None if boxes is None else np.ascontiguousarray(boxes, dtype=np.int32).reshape(B, 4)
         check(lib().og_unet_segment_u8(self._h, ptr(g), B, H, W, float(threshold), ptr(bx), ptr(mask), ptr(area),

@@ -50,7 +50,7 @@ def unet_segment_frame(frame_gray: np.ndarray, model, device=None, threshold: fl
         model.to(device)
     H, W = g.shape
     if (H, W) == (NET_SIZE, NET_SIZE):
-        mask, _, _ = model.segment(g[None], threshold=threshold, want_mask=True)
+        mask, _, _ = model.segment(g[None], threshold=threshold, want_mask=True, want_area=False)
         return mask[0]
     from .geometry import resize_linear
 
