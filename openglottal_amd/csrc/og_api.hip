@@ -2040,10 +2040,13 @@ static int stream_impl(og_unet* h, const uint8_t* frames, const uint8_t* const* 
         // one stream there is, more than moving 64 KB costs.  So the kernels read the frame from, and write the mask / area to, the
         // slot's PINNED host buffers directly (mapped into the device's address space; the writes are visible to the host once the
         // completion event has fired): no H2D, no D2H, no memset command.
-        const bool zc = single && nb <= 4 && h->zero_copy && !logits && (src == s.h_in || pinned);
+        bool zc = single && nb <= 4 && h->zero_copy && !logits && (src == s.h_in || pinned);
         uint8_t* z_in = nullptr; uint8_t* z_mask = nullptr; int32_t* z_area = nullptr; int32_t* z_boxes = nullptr;
+        if (zc && hipHostGetDevicePointer((void**)&z_in, (void*)src, 0) != hipSuccess) {
+            (void)hipGetLastError();   // a caller-pinned source that is not mapped into the device's address space: the copy path
+            zc = false;
+        }
         if (zc) {
-            HIPCHK(hipHostGetDevicePointer((void**)&z_in, (void*)src, 0));
             if (mask) HIPCHK(hipHostGetDevicePointer((void**)&z_mask, s.h_mask, 0));
             if (area) { HIPCHK(hipHostGetDevicePointer((void**)&z_area, s.h_area, 0)); memset(s.h_area, 0, (size_t)nb * 4); }
             if (boxes) { memcpy(s.h_boxes, boxes + 4 * (size_t)b0, (size_t)nb * 16); HIPCHK(hipHostGetDevicePointer((void**)&z_boxes, s.h_boxes, 0)); }
