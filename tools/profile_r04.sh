@@ -21,6 +21,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o bench -- python3 b
 echo "write rc=$?"
 F=$(find $O/fetch -name "*counter_collection.csv" | head -1); W=$(find $O/write -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_traffic.py "$F" "$W" $O/pmc_traffic_chunk64.json > $O/pmc_traffic_chunk64.txt; echo "pmc rc=$?"
+cp $O/pmc_traffic_chunk64.json profiles/r04_pmc_traffic_chunk64.json   # bench.py reads roofline.traffic from the newest profiles/*pmc_traffic_chunk64.json whose source sha matches
 S=$(find $O/stats -name "*kernel_stats.csv" | head -1); cp "$S" $O/kernel_stats_chunk64_lanes1.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o one -- python3 tools/one_frame_chains.py 2000 > $O/one_frame_chains_under_rocprof.txt 2> $O/stats1.err
 echo "stats1 rc=$?"
