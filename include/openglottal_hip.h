@@ -277,6 +277,13 @@ int og_yolo_num_anchors(og_yolo* h, int H, int W);    /* (H/8)(W/8)+(H/16)(W/16)
  *   pred [B,A,5] f32 or NULL: every decoded candidate (for NMS on the host / parity tests) */
 int og_yolo_detect_u8(og_yolo* h, const uint8_t* bgr, int B, int H, int W, float conf_thres, float* best, float* pred);
 int og_yolo_detect_u8_dev(og_yolo* h, const uint8_t* bgr_dev, int B, int H, int W, float conf_thres, float* best_dev, float* pred_dev);
+/* The same call in two halves, for callers that have something to run in between (round 4).  In the reference's frame loop
+ * (features.py:235-245) the detector's box only gates the COUNT of the U-Net's mask, so `detector.detect(frame)` (detector.py:58) and
+ * `unet_segment_frame(gray)` (utils.py:218-241) of one frame are independent: begin enqueues the detector's chain on its own stream
+ * and returns, the caller runs the U-Net call, end waits and delivers `best [B,5]`.  One call in flight per handle (anything else
+ * on the handle in between: OG_EINVAL); calls that do not take the latency path run inside begin. */
+int og_yolo_detect_u8_begin(og_yolo* h, const uint8_t* bgr, int B, int H, int W, float conf_thres);
+int og_yolo_detect_u8_end(og_yolo* h, float* best);
 int og_yolo_sync(og_yolo* h);
 /* Parity/debug: "model.0" ... "model.21" (module outputs), "box0..2", "cls0..2" (Detect branches), NCHW f32. */
 int og_yolo_get_activation(og_yolo* h, const char* name, int B, float* out_nchw, size_t capacity_floats, int* dims);

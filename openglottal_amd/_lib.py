@@ -84,6 +84,8 @@ PROTOTYPES = {
     "og_yolo_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "og_yolo_num_anchors": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "og_yolo_detect_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "og_yolo_detect_u8_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]),
+    "og_yolo_detect_u8_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "og_yolo_detect_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "og_yolo_sync": (C.c_int, [C.c_void_p]),
     "og_yolo_get_activation": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),

@@ -43,6 +43,22 @@ class TemporalDetector:
         xyxy, confs = self.model(frame_bgr, self.conf)
         return self.update(xyxy, confs, W, H)
 
+    def submit(self, frame_bgr: np.ndarray) -> None:
+        """``detect`` in two halves (an extension, not in the reference): ``submit(frame)`` starts the network on the detector's own
+        stream, ``result()`` waits for it and runs the state machine.  The reference's loop calls ``detect(frame)`` and then
+        ``unet_segment_frame(gray)`` (features.py:235-245); the mask does not depend on the box, so with ``submit`` before the U-Net
+        call and ``result`` after it the two networks overlap on the GPU.  Backends without ``submit`` run inside ``result``."""
+        self._pending_frame = frame_bgr
+        if hasattr(self.model, "submit"):
+            self.model.submit(frame_bgr, self.conf)
+
+    def result(self):
+        frame_bgr = self._pending_frame
+        self._pending_frame = None
+        H, W = frame_bgr.shape[:2]
+        xyxy, confs = self.model.result() if hasattr(self.model, "submit") else self.model(frame_bgr, self.conf)
+        return self.update(xyxy, confs, W, H)
+
     def update(self, xyxy, confs, W: int, H: int):
         """One step of the state machine given this frame's raw detections."""
         fresh = None

@@ -137,6 +137,37 @@ class YoloV8Detector:
             return np.zeros((0, 4), np.float32), np.zeros(0, np.float32)
         return b[None, :4].astype(np.float32), b[4:5].astype(np.float32)
 
+    def submit(self, frame_bgr: np.ndarray, conf: float = 0.25) -> None:
+        """First half of ``__call__`` (``og_yolo_detect_u8_begin``): letterbox on the host, enqueue the detector's chain on its own
+        stream, return.  ``result()`` delivers what ``__call__`` would have returned.  In the reference's frame loop
+        (features.py:235-245) the box only gates the count of the U-Net's mask, so the U-Net call of the same frame fits in between."""
+        f = np.asarray(frame_bgr)
+        if f.ndim == 2:
+            f = np.repeat(f[..., None], 3, axis=-1)
+        img, gain, px, py = letterbox_bgr(f, self.imgsz)
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        H, W = img.shape[:2]
+        check(lib().og_yolo_detect_u8_begin(self._h, ptr(img), 1, H, W, float(conf)), "og_yolo_detect_u8_begin")
+        self._pending = (f.shape[0], f.shape[1], gain, px, py)
+
+    def result(self):
+        """Second half of ``__call__``: ``(xyxy [n,4] f32, conf [n] f32)``, n ∈ {0,1}, in ORIGINAL frame pixels."""
+        if getattr(self, "_pending", None) is None:
+            raise OpenGlottalHipError("result() without submit()")
+        H0, W0, gain, px, py = self._pending
+        self._pending = None
+        best = np.empty((1, 5), np.float32)
+        check(lib().og_yolo_detect_u8_end(self._h, ptr(best)), "og_yolo_detect_u8_end")
+        b = best[0]
+        if b[4] < 0:
+            return np.zeros((0, 4), np.float32), np.zeros(0, np.float32)
+        if (gain, px, py) != (1.0, 0, 0):  # scale_boxes back to the original frame, as detect_frames
+            b[[0, 2]] = (b[[0, 2]] - np.float32(px)) / np.float32(gain)
+            b[[1, 3]] = (b[[1, 3]] - np.float32(py)) / np.float32(gain)
+        b[[0, 2]] = b[[0, 2]].clip(0, W0)
+        b[[1, 3]] = b[[1, 3]].clip(0, H0)
+        return b[None, :4].astype(np.float32), b[4:5].astype(np.float32)
+
     def activation(self, name: str, B: int = 1) -> np.ndarray:
         dims = (C.c_int * 3)()
         cap = 1 << 22

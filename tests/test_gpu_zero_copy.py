@@ -98,3 +98,35 @@ def test_detector_one_frame_call(net):
     for i, (x, y) in enumerate(zip(*outs)):
         assert np.array_equal(np.asarray(x), np.asarray(y))
         assert np.array_equal(np.asarray(y)[0], np.asarray(batched)[i])                 # and == the batched call
+
+
+def test_detector_submit_result_equals_detect_with_a_unet_call_in_between(net):
+    """`TemporalDetector.submit(frame)` ... `result()` (og_yolo_detect_u8_begin / _end) returns what `detect(frame)` returns, state
+    machine included, with the U-Net call of the same frame between the two halves; misuse is an error, not a hang."""
+    from openglottal_amd import TemporalDetector
+    from openglottal_amd.yolo import YoloV8Detector
+
+    m, bgr, gray = net
+    sd = synth.make_yolov8_state_dict(seed=7)
+    a = TemporalDetector(YoloV8Detector(sd, device="cuda:0"), conf=0.001)
+    b = TemporalDetector(YoloV8Detector(sd, device="cuda:0"), conf=0.001)
+    ref_mask, _, _ = m.segment(gray)
+    for i in range(len(bgr)):
+        want = a.detect(bgr[i])
+        b.submit(bgr[i])
+        mask = unet_segment_frame(gray[i], m)
+        got = b.result()
+        assert got == want, (i, got, want)
+        assert np.array_equal(mask, ref_mask[i])
+    odd = np.random.RandomState(3).randint(0, 256, (200, 312, 3), dtype=np.uint8)     # a frame the detector letterboxes
+    want = a.detect(odd)
+    b.submit(odd)
+    assert b.result() == want
+    b.model.submit(bgr[0], 0.25)
+    with pytest.raises(og.OpenGlottalHipError):
+        b.model.submit(bgr[1], 0.25)                 # one call in flight per handle
+    with pytest.raises(og.OpenGlottalHipError):
+        b.model.detect_batch(bgr[:1])
+    b.model.result()
+    with pytest.raises(og.OpenGlottalHipError):
+        b.model.result()
