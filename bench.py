@@ -172,6 +172,19 @@ def pipeline_legs(model, dev, chunk: int):
             pf[i] = float(np.sum(mask[y1:y2, x1:x2] > 0))
     gated["per_frame_loop"] = {"value": round(n_pf / (time.perf_counter() - t0), 1), "unit": "frames/s", "frames": n_pf,
                                "same_areas_as_streamed": bool(np.array_equal(pf, waves[502][:n_pf]))}
+    det.reset()
+    t0 = time.perf_counter()
+    po = np.zeros(n_pf)
+    for i, f in enumerate(bgr[:n_pf]):            # the same loop with the detector's chain started before / collected after the U-Net call
+        det.submit(f)
+        mask = unet_segment_frame(bgr_to_gray(f), model, dev)
+        box = det.result()
+        if box is not None:
+            x1, y1, x2, y2 = box
+            po[i] = float(np.sum(mask[y1:y2, x1:x2] > 0))
+    gated["per_frame_loop"]["detector_overlapped"] = {"value": round(n_pf / (time.perf_counter() - t0), 1), "unit": "frames/s",
+                                                      "same_areas": bool(np.array_equal(po, pf)),
+                                                      "note": "TemporalDetector.submit(frame) ... unet_segment_frame(gray) ... result(): the mask does not depend on the box"}
     t0 = time.perf_counter()
     frames, gts = synth.bagls_standin(3500)
     t_gen = time.perf_counter() - t0
