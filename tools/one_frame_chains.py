@@ -10,6 +10,12 @@ feats = (32, 64, 128, 256)
 m = og.UNet(1, 1, feats); m.load_state_dict(synth.make_unet_state_dict(feats, seed=20260227, head_scale=3.47, head_bias=-2.89)); m.to("cuda:0").eval()
 fr = torch.from_numpy(synth.bulk_gray_frames(256)).cuda(); area = torch.zeros(256, dtype=torch.int32, device="cuda")
 m.set_chunk(1); m.set_option("lanes", 1)
+for a in sys.argv[2:]:      # graphs=0 | any option name=value
+    k, v = a.split("=")
+    if k == "graphs":
+        m.set_graphs(bool(int(v)))
+    else:
+        m.set_option(k, int(v))
 m.segment_dev(fr, 256, 256, 256, area); m.sync()
 t0 = time.perf_counter()
 for _ in range(max(1, N // 256)):
