@@ -2045,21 +2045,25 @@ static int stream_impl(og_unet* h, const uint8_t* frames, const uint8_t* const* 
         // slot's PINNED host buffers directly (mapped into the device's address space; the writes are visible to the host once the
         // completion event has fired): no H2D, no D2H, no memset command.
         bool zc = single && nb <= 4 && h->zero_copy && !logits && (src == s.h_in || pinned);
-        uint8_t* z_in = nullptr; uint8_t* z_mask = nullptr; int32_t* z_area = nullptr; int32_t* z_boxes = nullptr;
+        uint8_t* z_in = nullptr;
+        uint8_t* z_mask = nullptr;
+        int32_t* z_area = nullptr;
+        int32_t* z_boxes = nullptr;
         if (zc && hipHostGetDevicePointer((void**)&z_in, (void*)src, 0) != hipSuccess) {
             (void)hipGetLastError();   // a caller-pinned source that is not mapped into the device's address space: the copy path
             zc = false;
         }
+        if (boxes) memcpy(s.h_boxes, boxes + 4 * (size_t)b0, (size_t)nb * 16);
         if (zc) {
             if (mask) HIPCHK(hipHostGetDevicePointer((void**)&z_mask, s.h_mask, 0));
-            if (area) { HIPCHK(hipHostGetDevicePointer((void**)&z_area, s.h_area, 0)); memset(s.h_area, 0, (size_t)nb * 4); }
-            if (boxes) { memcpy(s.h_boxes, boxes + 4 * (size_t)b0, (size_t)nb * 16); HIPCHK(hipHostGetDevicePointer((void**)&z_boxes, s.h_boxes, 0)); }
+            if (area) {
+                HIPCHK(hipHostGetDevicePointer((void**)&z_area, s.h_area, 0));
+                memset(s.h_area, 0, (size_t)nb * 4);
+            }
+            if (boxes) HIPCHK(hipHostGetDevicePointer((void**)&z_boxes, s.h_boxes, 0));
         } else {
-        HIPCHK(hipMemcpyAsync(s.d_in, src, nb * fb, hipMemcpyHostToDevice, s_in));
-        if (boxes) {
-            memcpy(s.h_boxes, boxes + 4 * (size_t)b0, (size_t)nb * 16);
-            HIPCHK(hipMemcpyAsync(s.d_boxes, s.h_boxes, (size_t)nb * 16, hipMemcpyHostToDevice, s_in));
-        }
+            HIPCHK(hipMemcpyAsync(s.d_in, src, nb * fb, hipMemcpyHostToDevice, s_in));
+            if (boxes) HIPCHK(hipMemcpyAsync(s.d_boxes, s.h_boxes, (size_t)nb * 16, hipMemcpyHostToDevice, s_in));
         }
         if (!single) {
             HIPCHK(hipEventRecord(s.ev_h2d, R.s_h2d));
