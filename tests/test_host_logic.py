@@ -110,6 +110,15 @@ def test_temporal_detector_traces_match_reference(golden_dir):
             b = det.detect(frame)
             outs.append(None if b is None else [int(v) for v in b])
         assert outs == t["out"], name
+        # the two-halves form (submit ... result: an extension next to the reference's detect) runs the same state machine
+        calls["i"] = 0
+        det2 = og.TemporalDetector(backend, **t["kw"])
+        outs2 = []
+        for _ in script:
+            det2.submit(frame)
+            b = det2.result()
+            outs2.append(None if b is None else [int(v) for v in b])
+        assert outs2 == t["out"], name
 
 
 def test_dice_iou_frame_metrics(golden_dir):
