@@ -9,7 +9,7 @@ for f in bench_default.json bench_under_rocprof_lanes1.json bench_c4_total_frame
          layer_profile_one_frame_per_chain.txt layer_profile_one_frame_per_chain_round3_kernels.txt \
          layer_profile_one_frame_per_chain_wave_split_everywhere.txt latency_one_frame_per_chain.txt timeline_one_frame_per_chain.txt \
          timeline_one_frame_per_chain_wave_split_everywhere.txt timeline_one_frame_per_chain_row_split_everywhere.txt \
-         ubench_wino1_chunk_mix.txt ubench_wino1_two_waves_per_simd.txt ubench_mfma_16x16x4_order.txt soak_wave_split_determinism.txt one_frame_chains_under_rocprof.txt \
+         ubench_wino1_chunk_mix.txt ubench_wino1_two_waves_per_simd.txt ubench_gather_policy.txt ubench_mfma_16x16x4_order.txt soak_wave_split_determinism.txt one_frame_chains_under_rocprof.txt \
          benchmark_video_speed_unet_only.txt benchmark_video_speed_gated.txt detector_and_unet_call_latency.txt \
          detector_batched_throughput.txt; do
     cp "$S/$f" "profiles/r04_$f"

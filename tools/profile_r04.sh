@@ -36,6 +36,7 @@ python3 tools/ps_timeline.py 1 wino_w=2 2>&1 | grep -v amdgpu > $O/timeline_one_
 python3 tools/ps_timeline.py 1 wino_w=4 2>&1 | grep -v amdgpu > $O/timeline_one_frame_per_chain_row_split_everywhere.txt
 tools/ubench/wino1_chunk_mix > $O/ubench_wino1_chunk_mix.txt 2>&1; echo "ubench rc=$?"
 tools/ubench/wino1_two_waves_per_simd > $O/ubench_wino1_two_waves_per_simd.txt 2>&1
+tools/ubench/gather_policy > $O/ubench_gather_policy.txt 2>&1
 tools/ubench/mfma_16x16x4_order > $O/ubench_mfma_16x16x4_order.txt 2>&1
 python3 tools/soak_w.py 8 2>&1 | grep -v amdgpu > $O/soak_wave_split_determinism.txt; echo "soak rc=$?"
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
