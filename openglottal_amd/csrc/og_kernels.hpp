@@ -93,6 +93,14 @@ __device__ __forceinline__ float og_act(float v, int act) {
 __device__ __forceinline__ void og_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // 16-byte LDS read from an absolute LDS byte address (no symbol-relative add: hipcc materialises `smem + x` as
 // "0 + x" per access once the control flow keeps it from hoisting that add)
+// a - b on four floats as TWO packed instructions: hipcc lowers a vector subtraction to four v_sub_f32 (an addition to two
+// v_pk_add_f32); v_pk_add_f32 with the negate modifier on the second source is the same IEEE subtraction, bit for bit
+__device__ __forceinline__ f32x4 og_sub4(f32x4 a, f32x4 b) {
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(f32x2{a.x, a.y}), "v"(f32x2{b.x, b.y}));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(f32x2{a.z, a.w}), "v"(f32x2{b.z, b.w}));
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
 __device__ __forceinline__ f32x4 og_lds_read16(unsigned addr) { return *(const OG_LDS_AS f32x4*)(unsigned long long)addr; }
 __device__ __forceinline__ unsigned og_lds_addr(const void* p) {
     return (unsigned)(size_t)((OG_LDS_AS const unsigned char*)p);
@@ -1251,12 +1259,12 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs a) {
     };
     auto row_op = [&](int n) {   // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first (n = 4 * row + j)
         const int r = n >> 2, j = n & 3;
-        t[n] = (r == 0) ? d[0 + j] - d[8 + j] : (r == 1) ? d[4 + j] + d[8 + j] : (r == 2) ? d[8 + j] - d[4 + j] : d[4 + j] - d[12 + j];
+        t[n] = (r == 0) ? og_sub4(d[0 + j], d[8 + j]) : (r == 1) ? d[4 + j] + d[8 + j] : (r == 2) ? og_sub4(d[8 + j], d[4 + j]) : og_sub4(d[4 + j], d[12 + j]);
     };
     auto col_op = [&](int n) {   // then columns (n = 4 * i + column)
         const int i = n >> 2, cc = n & 3;
-        tv[n] = (cc == 0) ? t[4 * i + 0] - t[4 * i + 2] : (cc == 1) ? t[4 * i + 1] + t[4 * i + 2] : (cc == 2) ? t[4 * i + 2] - t[4 * i + 1]
-                                                                                                           : t[4 * i + 1] - t[4 * i + 3];
+        tv[n] = (cc == 0) ? og_sub4(t[4 * i + 0], t[4 * i + 2]) : (cc == 1) ? t[4 * i + 1] + t[4 * i + 2] : (cc == 2) ? og_sub4(t[4 * i + 2], t[4 * i + 1])
+                                                                                                                     : og_sub4(t[4 * i + 1], t[4 * i + 3]);
     };
     auto v_write = [&](int k) { *(OG_LDS_AS f32x4*)(unsigned long long)(vwbase + (unsigned)(k * 4096)) = tv[k]; };
     // micro-op n of the transform pipeline of a group-1 (32 raw reads are 16: reads 0-15, row ops 16-31, column ops 32-47, lo writes 48-55)
@@ -1562,7 +1570,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_ps(ConvArgs a) {
             else if (PN == 2) {   // t = columns (0,1,2) -> c0 = t0 - t2, c1 = t1 + t2 | columns (1,2,3) -> c2 = t2 - t1 = t[1] - t[0], c3 = t1 - t3 = t[0] - t[2]
                 if (k == 0) v = pc0 ? fma4(-1.0f, t[0], t[1]) : fma4(-1.0f, t[2], t[0]);
                 else v = pc0 ? fma4(-1.0f, t[2], t[0]) : fma4(1.0f, t[2], t[1]);
-            } else v = (k == 0) ? t[0] - t[2] : (k == 1) ? t[1] + t[2] : (k == 2) ? t[2] - t[1] : t[1] - t[3];
+            } else v = (k == 0) ? og_sub4(t[0], t[2]) : (k == 1) ? t[1] + t[2] : (k == 2) ? og_sub4(t[2], t[1]) : og_sub4(t[1], t[3]);
             *(OG_LDS_AS f32x4*)(unsigned long long)(vwbase + (unsigned)(((ck & 1) * PN + k) * 4096)) = v;
         }
     };
@@ -1827,10 +1835,10 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w(ConvArgs a) {
     f32x4 t[WB][4];
     auto xf = [&](int wb, int n, int to) {
         if (n < 4) t[wb][n] = fma4(rsgn, rd[wb][1][n], rd[wb][0][n]);
-        else if (n == 4) tv[to][wb][0] = t[wb][0] - t[wb][2];
+        else if (n == 4) tv[to][wb][0] = og_sub4(t[wb][0], t[wb][2]);
         else if (n == 5) tv[to][wb][1] = t[wb][1] + t[wb][2];
-        else if (n == 6) tv[to][wb][2] = t[wb][2] - t[wb][1];
-        else tv[to][wb][3] = t[wb][1] - t[wb][3];
+        else if (n == 6) tv[to][wb][2] = og_sub4(t[wb][2], t[wb][1]);
+        else tv[to][wb][3] = og_sub4(t[wb][1], t[wb][3]);
     };
 
     // workgroup barrier WITHOUT a fence: __syncthreads() would make hipcc wait vmcnt(0) for the loads it tracks (scale / shift), i.e.
