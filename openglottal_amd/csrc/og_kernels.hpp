@@ -101,6 +101,12 @@ __device__ __forceinline__ f32x4 og_sub4(f32x4 a, f32x4 b) {
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(f32x2{a.z, a.w}), "v"(f32x2{b.z, b.w}));
     return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
+__device__ __forceinline__ f32x4 og_add4(f32x4 a, f32x4 b) {   // (hipcc packs most vector additions itself, not all)
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(f32x2{a.x, a.y}), "v"(f32x2{b.x, b.y}));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(f32x2{a.z, a.w}), "v"(f32x2{b.z, b.w}));
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
 __device__ __forceinline__ f32x4 og_lds_read16(unsigned addr) { return *(const OG_LDS_AS f32x4*)(unsigned long long)addr; }
 __device__ __forceinline__ unsigned og_lds_addr(const void* p) {
     return (unsigned)(size_t)((OG_LDS_AS const unsigned char*)p);
@@ -1556,8 +1562,12 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_ps(ConvArgs a) {
             xb[n] = og_lds_read16(rb_ + (unsigned)((rb * RP + (j & 1) * 9 + (j >> 1)) * PB));
         }
     };
-    auto fma4 = [](float sgn, f32x4 b_, f32x4 a_) {
-        return f32x4{fmaf(sgn, b_.x, a_.x), fmaf(sgn, b_.y, a_.y), fmaf(sgn, b_.z, a_.z), fmaf(sgn, b_.w, a_.w)};
+    auto fma4 = [](float sgn, f32x4 b_, f32x4 a_) {   // sgn * b + a as two v_pk_fma_f32 (hipcc emits four v_fma_f32 for it; same fused rounding)
+        const f32x2 s2 = {sgn, sgn};
+        f32x2 lo, hi;
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(s2), "v"(f32x2{b_.x, b_.y}), "v"(f32x2{a_.x, a_.y}));
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(s2), "v"(f32x2{b_.z, b_.w}), "v"(f32x2{a_.z, a_.w}));
+        return f32x4{lo.x, lo.y, hi.x, hi.y};
     };
     auto tr_write = [&](int ck) {   // -> V[ck & 1][0 .. PN)
         f32x4 t[NCOL];
@@ -1570,7 +1580,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_ps(ConvArgs a) {
             else if (PN == 2) {   // t = columns (0,1,2) -> c0 = t0 - t2, c1 = t1 + t2 | columns (1,2,3) -> c2 = t2 - t1 = t[1] - t[0], c3 = t1 - t3 = t[0] - t[2]
                 if (k == 0) v = pc0 ? fma4(-1.0f, t[0], t[1]) : fma4(-1.0f, t[2], t[0]);
                 else v = pc0 ? fma4(-1.0f, t[2], t[0]) : fma4(1.0f, t[2], t[1]);
-            } else v = (k == 0) ? og_sub4(t[0], t[2]) : (k == 1) ? t[1] + t[2] : (k == 2) ? og_sub4(t[2], t[1]) : og_sub4(t[1], t[3]);
+            } else v = (k == 0) ? og_sub4(t[0], t[2]) : (k == 1) ? og_add4(t[1], t[2]) : (k == 2) ? og_sub4(t[2], t[1]) : og_sub4(t[1], t[3]);
             *(OG_LDS_AS f32x4*)(unsigned long long)(vwbase + (unsigned)(((ck & 1) * PN + k) * 4096)) = v;
         }
     };
@@ -1821,8 +1831,12 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w(ConvArgs a) {
         }
 
     f32x4 tv[2][WB][4], bv[2][4], rd[WB][2][4];
-    auto fma4 = [](float sgn, f32x4 b_, f32x4 a_) {
-        return f32x4{fmaf(sgn, b_.x, a_.x), fmaf(sgn, b_.y, a_.y), fmaf(sgn, b_.z, a_.z), fmaf(sgn, b_.w, a_.w)};
+    auto fma4 = [](float sgn, f32x4 b_, f32x4 a_) {   // sgn * b + a as two v_pk_fma_f32 (hipcc emits four v_fma_f32 for it; same fused rounding)
+        const f32x2 s2 = {sgn, sgn};
+        f32x2 lo, hi;
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(s2), "v"(f32x2{b_.x, b_.y}), "v"(f32x2{a_.x, a_.y}));
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(s2), "v"(f32x2{b_.z, b_.w}), "v"(f32x2{a_.z, a_.w}));
+        return f32x4{lo.x, lo.y, hi.x, hi.y};
     };
     constexpr int NR = 8 * WB;   // raw patch reads per chunk: index r = (block, row select, patch column)
     unsigned rcur[2][4];   // rbase + the ring buffer of the stage being read (8 adds per stage, not one per read)
@@ -1836,7 +1850,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w(ConvArgs a) {
     auto xf = [&](int wb, int n, int to) {
         if (n < 4) t[wb][n] = fma4(rsgn, rd[wb][1][n], rd[wb][0][n]);
         else if (n == 4) tv[to][wb][0] = og_sub4(t[wb][0], t[wb][2]);
-        else if (n == 5) tv[to][wb][1] = t[wb][1] + t[wb][2];
+        else if (n == 5) tv[to][wb][1] = og_add4(t[wb][1], t[wb][2]);
         else if (n == 6) tv[to][wb][2] = og_sub4(t[wb][2], t[wb][1]);
         else tv[to][wb][3] = og_sub4(t[wb][1], t[wb][3]);
     };
@@ -2112,8 +2126,12 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_wp(ConvArgs a) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     asm volatile("" : "+a"(acc));
     f32x4 tv[2], bv[2], rd[2][2];
-    auto fma4 = [](float sgn, f32x4 b_, f32x4 a_) {
-        return f32x4{fmaf(sgn, b_.x, a_.x), fmaf(sgn, b_.y, a_.y), fmaf(sgn, b_.z, a_.z), fmaf(sgn, b_.w, a_.w)};
+    auto fma4 = [](float sgn, f32x4 b_, f32x4 a_) {   // sgn * b + a as two v_pk_fma_f32 (hipcc emits four v_fma_f32 for it; same fused rounding)
+        const f32x2 s2 = {sgn, sgn};
+        f32x2 lo, hi;
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(s2), "v"(f32x2{b_.x, b_.y}), "v"(f32x2{a_.x, a_.y}));
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(s2), "v"(f32x2{b_.z, b_.w}), "v"(f32x2{a_.z, a_.w}));
+        return f32x4{lo.x, lo.y, hi.x, hi.y};
     };
     auto read_raw = [&](int r, int j) { rd[r >> 1][r & 1] = og_lds_read16(rcur[r >> 1][r & 1] + (unsigned)(j * GSTRIDE)); };
     auto xform = [&](int to) {   // rows first (t = x[ra] +- x[rb] for the two columns), then the column op: k_conv_wino's order
