@@ -20,6 +20,14 @@ __device__ __forceinline__ void glds16b(unsigned voff, i32x4 rsrc, unsigned soff
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds) : "memory");
 }
+// a - b as two v_pk_add_f32 with the negate modifier (hipcc lowers a vector subtraction to four v_sub_f32): what the kernels do since round 4
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(f2{a.x, a.y}), "v"(f2{b.x, b.y}));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(f2{a.z, a.w}), "v"(f2{b.z, b.w}));
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
 __device__ __forceinline__ f32x4 ldsr(unsigned a) { return *(const LDS_AS f32x4*)(unsigned long long)a; }
 __device__ __forceinline__ void ldsw(unsigned a, f32x4 v) { *(LDS_AS f32x4*)(unsigned long long)a = v; }
 constexpr int RAW = 19584, VB = 65536, UG = 8192, LDS_BYTES = RAW + VB + 2 * UG;
@@ -67,8 +75,8 @@ __global__ __launch_bounds__(256, 1) void k(const float* g, size_t g_bytes, floa
     for (int n = 0; n < 16; ++n) d[n] = t[n] = tv[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto xf_op = [&](int n) {
         if (n < 16) d[n] = ldsr(rbase + (unsigned)(((n >> 2) * 18 + (n & 1) * 9 + ((n & 3) >> 1)) * 32));
-        else if (n < 32) { const int r = (n - 16) >> 2, j = n & 3; t[n - 16] = (r == 0) ? d[j] - d[8 + j] : (r == 1) ? d[4 + j] + d[8 + j] : (r == 2) ? d[8 + j] - d[4 + j] : d[4 + j] - d[12 + j]; }
-        else if (n < 48) { const int i = (n - 32) >> 2, cc = n & 3; tv[n - 32] = (cc == 0) ? t[4 * i] - t[4 * i + 2] : (cc == 1) ? t[4 * i + 1] + t[4 * i + 2] : (cc == 2) ? t[4 * i + 2] - t[4 * i + 1] : t[4 * i + 1] - t[4 * i + 3]; }
+        else if (n < 32) { const int r = (n - 16) >> 2, j = n & 3; t[n - 16] = (r == 0) ? sub4(d[j], d[8 + j]) : (r == 1) ? d[4 + j] + d[8 + j] : (r == 2) ? sub4(d[8 + j], d[4 + j]) : sub4(d[4 + j], d[12 + j]); }
+        else if (n < 48) { const int i = (n - 32) >> 2, cc = n & 3; tv[n - 32] = (cc == 0) ? sub4(t[4 * i], t[4 * i + 2]) : (cc == 1) ? t[4 * i + 1] + t[4 * i + 2] : (cc == 2) ? sub4(t[4 * i + 2], t[4 * i + 1]) : sub4(t[4 * i + 1], t[4 * i + 3]); }
         else if (n < 56) ldsw(vwbase + (unsigned)((n - 48) * 4096), tv[n - 48]);
     };
     auto xf4 = [&](int n) { xf_op(n); xf_op(n + 1); xf_op(n + 2); xf_op(n + 3); };

@@ -22,6 +22,19 @@ __device__ __forceinline__ void glds16b(unsigned voff, i32x4 rsrc, unsigned soff
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds) : "memory");
 }
+// a - b as two v_pk_add_f32 with the negate modifier (hipcc lowers a vector subtraction to four v_sub_f32): what the kernels do since round 4
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(f2{a.x, a.y}), "v"(f2{b.x, b.y}));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(f2{a.z, a.w}), "v"(f2{b.z, b.w}));
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ f32x2 sub2(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ f32x4 ldsr(unsigned a) { return *(const LDS_AS f32x4*)(unsigned long long)a; }
 __device__ __forceinline__ f32x2 ldsr2(unsigned a) { return *(const LDS_AS f32x2*)(unsigned long long)a; }
 __device__ __forceinline__ void ldsw2(unsigned a, f32x2 v) { *(LDS_AS f32x2*)(unsigned long long)a = v; }
@@ -79,13 +92,13 @@ __global__ __launch_bounds__(256 * WPS, 1) void k(const float* g, size_t g_bytes
     auto xf_op = [&](int n) {   // 0-15 raw reads, 16-31 row ops, 32-47 column ops, 48-55 lo V writes (hi writes 56-63 issued in the other group)
         if (WPS == 1) {
             if (n < 16) d4[n] = ldsr(rbase + (unsigned)(((n >> 2) * 18 + (n & 1) * 9 + ((n & 3) >> 1)) * 32));
-            else if (n < 32) { const int r = (n - 16) >> 2, j = n & 3; t4[n - 16] = (r == 0) ? d4[j] - d4[8 + j] : (r == 1) ? d4[4 + j] + d4[8 + j] : (r == 2) ? d4[8 + j] - d4[4 + j] : d4[4 + j] - d4[12 + j]; }
-            else if (n < 48) { const int i = (n - 32) >> 2, cc = n & 3; v4[n - 32] = (cc == 0) ? t4[4 * i] - t4[4 * i + 2] : (cc == 1) ? t4[4 * i + 1] + t4[4 * i + 2] : (cc == 2) ? t4[4 * i + 2] - t4[4 * i + 1] : t4[4 * i + 1] - t4[4 * i + 3]; }
+            else if (n < 32) { const int r = (n - 16) >> 2, j = n & 3; t4[n - 16] = (r == 0) ? sub4(d4[j], d4[8 + j]) : (r == 1) ? d4[4 + j] + d4[8 + j] : (r == 2) ? sub4(d4[8 + j], d4[4 + j]) : sub4(d4[4 + j], d4[12 + j]); }
+            else if (n < 48) { const int i = (n - 32) >> 2, cc = n & 3; v4[n - 32] = (cc == 0) ? sub4(t4[4 * i], t4[4 * i + 2]) : (cc == 1) ? t4[4 * i + 1] + t4[4 * i + 2] : (cc == 2) ? sub4(t4[4 * i + 2], t4[4 * i + 1]) : sub4(t4[4 * i + 1], t4[4 * i + 3]); }
             else if (n < 64) ldsw(vwbase + (unsigned)((n - 48) * 4096), v4[n - 48]);
         } else {
             if (n < 16) d2[n] = ldsr2(rbase + (unsigned)(((n >> 2) * 18 + (n & 1) * 9 + ((n & 3) >> 1)) * 32));
-            else if (n < 32) { const int r = (n - 16) >> 2, j = n & 3; t2[n - 16] = (r == 0) ? d2[j] - d2[8 + j] : (r == 1) ? d2[4 + j] + d2[8 + j] : (r == 2) ? d2[8 + j] - d2[4 + j] : d2[4 + j] - d2[12 + j]; }
-            else if (n < 48) { const int i = (n - 32) >> 2, cc = n & 3; v2[n - 32] = (cc == 0) ? t2[4 * i] - t2[4 * i + 2] : (cc == 1) ? t2[4 * i + 1] + t2[4 * i + 2] : (cc == 2) ? t2[4 * i + 2] - t2[4 * i + 1] : t2[4 * i + 1] - t2[4 * i + 3]; }
+            else if (n < 32) { const int r = (n - 16) >> 2, j = n & 3; t2[n - 16] = (r == 0) ? sub2(d2[j], d2[8 + j]) : (r == 1) ? d2[4 + j] + d2[8 + j] : (r == 2) ? sub2(d2[8 + j], d2[4 + j]) : sub2(d2[4 + j], d2[12 + j]); }
+            else if (n < 48) { const int i = (n - 32) >> 2, cc = n & 3; v2[n - 32] = (cc == 0) ? sub2(t2[4 * i], t2[4 * i + 2]) : (cc == 1) ? t2[4 * i + 1] + t2[4 * i + 2] : (cc == 2) ? sub2(t2[4 * i + 2], t2[4 * i + 1]) : sub2(t2[4 * i + 1], t2[4 * i + 3]); }
             else if (n < 64) ldsw2(vwbase + (unsigned)((n - 48) * 4096), v2[n - 48]);
         }
     };
